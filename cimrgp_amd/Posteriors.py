@@ -1,0 +1,130 @@
+"""Per-layer exact-GP posterior over the regions of one resolution.
+
+Dense twin of the reference's ``Posterior`` (Posteriors.py:9-211): constructed
+per layer, holds per-region state in lists indexed by region, and is updated
+IN PLACE from lists indexed by region (Posteriors.py:35,81,113).  Where the
+reference's ``update_scale_given_axis`` forms a diagonal precision and the
+projected targets y~ (Posteriors.py:35-78), this class builds the RBF Gram
+matrix of the region, factors it and solves for the weights -- D1, D2, D3 of
+SURVEY.md 8a' -- through the hand-written HIP kernels.
+"""
+import numpy as np
+import torch
+
+from . import device as dev
+
+NOISE_FRACTION = 0.01    # RegressionInput.py:62: labels.var() * 0.01
+NOISE_FLOOR = 1e-8       # x sf: keeps a constant-target block positive definite
+
+
+class DenseBlock(object):
+    """Device-resident state of one (resolution, region) block."""
+
+    def __init__(self, x, kernel):
+        self.x = x                       # (n x d) device view, normalised inputs
+        self.n = int(x.shape[0])
+        self.kernel = kernel
+        self.lbuf = None                 # padded (n x ld) buffer holding L in its lower triangle
+        self.ws = None                   # inverted diagonal blocks (potrf workspace)
+        self.info = None                 # device int32, LAPACK convention
+        self.alpha = None                # (n x q)  (K + noise I)^-1 r
+        self.z = None                    # (n x q)  L^-1 r
+        self.bias = None                 # (q,) device
+        self.noise = None                # (1,) device
+        self.r = None
+
+    def fit(self, y, f_bar, train_out, shared_bias=None, shared_noise=None, keep_factor=True):
+        """Fit on targets ``y - f_bar`` (both (n x q) device views); adds this
+        block's training-point prediction into ``train_out`` (n x q)."""
+        q = y.shape[1]
+        k = self.kernel
+        stats = None
+        if shared_bias is None or (shared_noise is None and k.noise is None):
+            stats = dev.block_stats(y, f_bar)
+        self.bias = stats[:q] if shared_bias is None else shared_bias
+        if k.noise is not None:
+            self.noise = torch.full((1,), k.noise, dtype=y.dtype, device=y.device)
+        elif shared_noise is not None:
+            self.noise = shared_noise
+        else:
+            self.noise = dev.noise_from_stats(stats, q, NOISE_FRACTION, NOISE_FLOOR * k.sf)
+        self.r = dev.residual(y, f_bar, self.bias)
+        self.lbuf = dev.rbf_gram(self.x, k.l, k.sf, 0.0, lower_only=True)
+        dev.add_diag(self.lbuf, self.n, self.noise)
+        self.ws, self.info = dev.potrf(self.lbuf, self.n)
+        self.alpha = self.r.clone()
+        self.z = dev.potrs(self.lbuf, self.n, self.ws, self.alpha, want_z=True)
+        # K_noiseless alpha = r - noise * alpha: no second pass over the Gram matrix
+        dev.train_mean(self.r, self.alpha, self.bias, self.noise, train_out, accumulate=True)
+        if not keep_factor:
+            self.lbuf = None
+            self.ws = None
+            self.z = None
+        self.r = None
+
+    def predict(self, xs, mean_out, var_out=None, extra_var=0.0, chunk=16384):
+        """Accumulate this block's predictive mean (and latent variance) at ``xs``
+        into ``mean_out`` (ns x q) / ``var_out`` (ns,)."""
+        k = self.kernel
+        if var_out is None:
+            dev.predict_mean(self.x, self.alpha, xs, k.l, k.sf, self.bias, out=mean_out, accumulate=True)
+            return
+        if self.lbuf is None:
+            raise RuntimeError('predictive variance needs the Cholesky factor: fit with keep_factors=True')
+        ns = xs.shape[0]
+        for s0 in range(0, ns, chunk):
+            s1 = min(ns, s0 + chunk)
+            w = dev.rbf_cross(xs[s0:s1], self.x, k.l, k.sf)
+            dev.trsm_rows(self.lbuf, self.n, self.ws, w, s1 - s0)
+            dev.predict_from_w(w, s1 - s0, self.n, self.z, k.sf, extra_var, self.bias,
+                               mean_out[s0:s1], var_out[s0:s1], accumulate=True)
+
+    def log_marginal_likelihood(self, r_dot_alpha):
+        """-1/2 r^T alpha - sum log L_ii - n/2 log 2pi, per output column summed."""
+        half_logdet = float(dev.logdet_half(self.lbuf, self.n).item())
+        q = self.alpha.shape[1]
+        return -0.5 * r_dot_alpha - q * half_logdet - 0.5 * q * self.n * np.log(2 * np.pi)
+
+
+class DensePosterior(object):
+    """One resolution: a list of :class:`DenseBlock`, updated in place."""
+
+    def __init__(self, n_regions, dy, kernel, noise_region_specific=True, bias_region_specific=True):
+        self.n_regions = int(n_regions)
+        self.dy = int(dy)
+        self.kernel = kernel
+        self.noise_region_specific = noise_region_specific
+        self.bias_region_specific = bias_region_specific
+        self.blocks = [None] * self.n_regions
+
+    def update_scale_given_axis(self, y_mean, x, f_bar, train_out, owned=None, keep_factors=True):
+        """``y_mean``, ``x``, ``f_bar``, ``train_out``: lists indexed by region of device
+        views (the reference passes lists indexed by region too, Posteriors.py:35).
+        ``owned``: iterable of the region ids this process computes (default all)."""
+        regions = range(self.n_regions) if owned is None else owned
+        shared_bias = shared_noise = None
+        if not (self.bias_region_specific and (self.noise_region_specific or self.kernel.noise is not None)):
+            # layer-wide statistics over the concatenation of all regions (regions are
+            # contiguous slices of one array: region 0's base with the total length)
+            y_all, f_all = self._whole_layer(y_mean), self._whole_layer(f_bar)
+            stats = dev.block_stats(y_all, f_all)
+            if not self.bias_region_specific:
+                shared_bias = stats[:self.dy]
+            if not self.noise_region_specific and self.kernel.noise is None:
+                shared_noise = dev.noise_from_stats(stats, self.dy, NOISE_FRACTION, NOISE_FLOOR * self.kernel.sf)
+        for l in regions:
+            blk = DenseBlock(x[l], self.kernel)
+            blk.fit(y_mean[l], f_bar[l], train_out[l], shared_bias, shared_noise, keep_factor=keep_factors)
+            self.blocks[l] = blk
+
+    @staticmethod
+    def _whole_layer(views):
+        base = views[0]
+        total = sum(int(v.shape[0]) for v in views)
+        return torch.as_strided(base, (total, base.shape[1]), base.stride())
+
+    def check(self, regions=None):
+        """Raise ``numpy.linalg.LinAlgError`` if any factorisation met a non-positive pivot."""
+        for l in (range(self.n_regions) if regions is None else regions):
+            if self.blocks[l] is not None and self.blocks[l].info is not None:
+                dev.raise_if_not_pd(self.blocks[l].info)

@@ -1,0 +1,229 @@
+// extern "C" entry points of libcimrgp.so (declared in include/cimrgp.h).
+#include "common.hpp"
+
+#include <string.h>
+
+namespace cimrgp {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+int fail(const char* fn, const char* what)
+{
+    g_last_error = std::string(fn) + ": " + what;
+    return -1;
+}
+
+int check_hip(hipError_t e, const char* fn, const char* what)
+{
+    if (e == hipSuccess) return 0;
+    g_last_error = std::string(fn) + ": " + what + ": " + hipGetErrorString(e);
+    return -2;
+}
+
+}  // namespace cimrgp
+
+using namespace cimrgp;
+
+#define DISPATCH(dtype, fn, CALL_F32, CALL_F64)                  \
+    switch (dtype) {                                             \
+        case CIMRGP_F32: return CALL_F32;                        \
+        case CIMRGP_F64: return CALL_F64;                        \
+        default: return fail(fn, "unknown dtype");               \
+    }
+
+static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline size_t esize(int dtype) { return dtype == CIMRGP_F64 ? 8 : 4; }
+static inline bool ld_ok(int dtype, int64_t ld) { return ld % (dtype == CIMRGP_F64 ? 2 : 4) == 0; }
+
+extern "C" {
+
+int cimrgp_version(void) { return 100; }
+
+const char* cimrgp_last_error(void) { return g_last_error.c_str(); }
+
+int cimrgp_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int cimrgp_rbf_gram(int dtype, const void* x_dev, int64_t n, int d, double ell, double sf2, double diag_add,
+                    void* k_dev, int64_t ldk, int lower_only, void* stream)
+{
+    const char* fn = "cimrgp_rbf_gram";
+    CIMRGP_REQUIRE(x_dev && k_dev, fn, "null pointer");
+    CIMRGP_REQUIRE(n >= 0, fn, "negative size");
+    DISPATCH(dtype, fn,
+             rbf_gram_run<float>((const float*)x_dev, n, (const float*)x_dev, n, d, ell, sf2, diag_add, (float*)k_dev, ldk,
+                                 true, lower_only != 0, S(stream)),
+             rbf_gram_run<double>((const double*)x_dev, n, (const double*)x_dev, n, d, ell, sf2, diag_add, (double*)k_dev,
+                                  ldk, true, lower_only != 0, S(stream)));
+}
+
+int cimrgp_rbf_cross(int dtype, const void* xa_dev, int64_t na, const void* xb_dev, int64_t nb, int d, double ell,
+                     double sf2, void* kab_dev, int64_t ld, void* stream)
+{
+    const char* fn = "cimrgp_rbf_cross";
+    CIMRGP_REQUIRE(xa_dev && xb_dev && kab_dev, fn, "null pointer");
+    CIMRGP_REQUIRE(na >= 0 && nb >= 0, fn, "negative size");
+    DISPATCH(dtype, fn,
+             rbf_gram_run<float>((const float*)xa_dev, na, (const float*)xb_dev, nb, d, ell, sf2, 0.0, (float*)kab_dev, ld,
+                                 false, false, S(stream)),
+             rbf_gram_run<double>((const double*)xa_dev, na, (const double*)xb_dev, nb, d, ell, sf2, 0.0, (double*)kab_dev,
+                                  ld, false, false, S(stream)));
+}
+
+size_t cimrgp_potrf_workspace_bytes(int dtype, int64_t n)
+{
+    if (n <= 0) return 0;
+    const int64_t slabs = (n + 63) / 64;
+    return (size_t)slabs * 64 * 64 * esize(dtype);
+}
+
+int cimrgp_potrf(int dtype, void* k_dev, int64_t n, int64_t ldk, void* workspace_dev, size_t workspace_bytes,
+                 int32_t* info_dev, void* stream)
+{
+    const char* fn = "cimrgp_potrf";
+    CIMRGP_REQUIRE(k_dev && workspace_dev && info_dev, fn, "null pointer");
+    CIMRGP_REQUIRE(n >= 0 && ldk >= n, fn, "bad dimensions");
+    CIMRGP_REQUIRE(dtype == CIMRGP_F32 || dtype == CIMRGP_F64, fn, "unknown dtype");
+    CIMRGP_REQUIRE(ld_ok(dtype, ldk), fn, "leading dimension must be a multiple of 16 bytes");
+    CIMRGP_REQUIRE(aligned16(k_dev) && aligned16(workspace_dev), fn, "pointers must be 16-byte aligned");
+    CIMRGP_REQUIRE(workspace_bytes >= cimrgp_potrf_workspace_bytes(dtype, n), fn, "workspace too small");
+    if (n == 0) return check_hip(hipMemsetAsync(info_dev, 0, sizeof(int32_t), S(stream)), fn, "memset");
+    DISPATCH(dtype, fn,
+             potrf_run<float>((float*)k_dev, n, ldk, (float*)workspace_dev, info_dev, S(stream)),
+             potrf_run<double>((double*)k_dev, n, ldk, (double*)workspace_dev, info_dev, S(stream)));
+}
+
+int cimrgp_potrs(int dtype, const void* l_dev, int64_t n, int64_t ldl, const void* workspace_dev, void* rhs_dev, int q,
+                 void* z_dev, void* scratch_dev, void* stream)
+{
+    const char* fn = "cimrgp_potrs";
+    CIMRGP_REQUIRE(l_dev && workspace_dev && rhs_dev && scratch_dev, fn, "null pointer");
+    CIMRGP_REQUIRE(n >= 0 && ldl >= n, fn, "bad dimensions");
+    DISPATCH(dtype, fn,
+             potrs_run<float>((const float*)l_dev, n, ldl, (const float*)workspace_dev, (float*)rhs_dev, q, (float*)z_dev,
+                              (float*)scratch_dev, S(stream)),
+             potrs_run<double>((const double*)l_dev, n, ldl, (const double*)workspace_dev, (double*)rhs_dev, q,
+                               (double*)z_dev, (double*)scratch_dev, S(stream)));
+}
+
+int cimrgp_trsm_rows(int dtype, const void* l_dev, int64_t n, int64_t ldl, const void* workspace_dev, void* b_dev,
+                     int64_t m, int64_t ldb, void* stream)
+{
+    const char* fn = "cimrgp_trsm_rows";
+    CIMRGP_REQUIRE(l_dev && workspace_dev && b_dev, fn, "null pointer");
+    CIMRGP_REQUIRE(n >= 0 && m >= 0 && ldl >= n && ldb >= n, fn, "bad dimensions");
+    CIMRGP_REQUIRE(dtype == CIMRGP_F32 || dtype == CIMRGP_F64, fn, "unknown dtype");
+    CIMRGP_REQUIRE(ld_ok(dtype, ldl) && ld_ok(dtype, ldb), fn, "leading dimensions must be multiples of 16 bytes");
+    CIMRGP_REQUIRE(aligned16(l_dev) && aligned16(b_dev) && aligned16(workspace_dev), fn, "pointers must be 16-byte aligned");
+    if (n == 0 || m == 0) return 0;
+    DISPATCH(dtype, fn,
+             solve_rows_run<float>((const float*)l_dev, n, ldl, (const float*)workspace_dev, (float*)b_dev, m, ldb, S(stream)),
+             solve_rows_run<double>((const double*)l_dev, n, ldl, (const double*)workspace_dev, (double*)b_dev, m, ldb,
+                                    S(stream)));
+}
+
+int cimrgp_predict_mean(int dtype, const void* x_dev, int64_t n, int d, const void* alpha_dev, int q, const void* xs_dev,
+                        int64_t ns, double ell, double sf2, const void* bias_dev, void* mean_dev, int accumulate,
+                        void* stream)
+{
+    const char* fn = "cimrgp_predict_mean";
+    CIMRGP_REQUIRE(x_dev && alpha_dev && xs_dev && mean_dev, fn, "null pointer");
+    CIMRGP_REQUIRE(n >= 0 && ns >= 0, fn, "negative size");
+    DISPATCH(dtype, fn,
+             predict_mean_run<float>((const float*)x_dev, n, d, (const float*)alpha_dev, q, (const float*)xs_dev, ns, ell,
+                                     sf2, (const float*)bias_dev, (float*)mean_dev, accumulate, S(stream)),
+             predict_mean_run<double>((const double*)x_dev, n, d, (const double*)alpha_dev, q, (const double*)xs_dev, ns,
+                                      ell, sf2, (const double*)bias_dev, (double*)mean_dev, accumulate, S(stream)));
+}
+
+int cimrgp_predict_from_w(int dtype, const void* w_dev, int64_t ns, int64_t n, int64_t ldw, const void* z_dev, int q,
+                          double sf2, double extra_var, const void* bias_dev, void* mean_dev, void* var_dev,
+                          int accumulate, void* stream)
+{
+    const char* fn = "cimrgp_predict_from_w";
+    CIMRGP_REQUIRE(w_dev, fn, "null pointer");
+    CIMRGP_REQUIRE(ns >= 0 && n >= 0 && ldw >= n, fn, "bad dimensions");
+    CIMRGP_REQUIRE(mean_dev == nullptr || z_dev != nullptr, fn, "mean requested without z");
+    DISPATCH(dtype, fn,
+             predict_from_w_run<float>((const float*)w_dev, ns, n, ldw, (const float*)z_dev, q, sf2, extra_var,
+                                       (const float*)bias_dev, (float*)mean_dev, (float*)var_dev, accumulate, S(stream)),
+             predict_from_w_run<double>((const double*)w_dev, ns, n, ldw, (const double*)z_dev, q, sf2, extra_var,
+                                        (const double*)bias_dev, (double*)mean_dev, (double*)var_dev, accumulate,
+                                        S(stream)));
+}
+
+int cimrgp_block_stats(int dtype, const void* y_dev, const void* fbar_dev, int64_t n, int q, void* stats_dev, void* stream)
+{
+    const char* fn = "cimrgp_block_stats";
+    CIMRGP_REQUIRE(y_dev && stats_dev, fn, "null pointer");
+    DISPATCH(dtype, fn,
+             misc_block_stats<float>((const float*)y_dev, (const float*)fbar_dev, n, q, (float*)stats_dev, S(stream)),
+             misc_block_stats<double>((const double*)y_dev, (const double*)fbar_dev, n, q, (double*)stats_dev, S(stream)));
+}
+
+int cimrgp_residual(int dtype, const void* y_dev, const void* fbar_dev, const void* bias_dev, int64_t n, int q,
+                    void* r_dev, void* stream)
+{
+    const char* fn = "cimrgp_residual";
+    CIMRGP_REQUIRE(y_dev && r_dev, fn, "null pointer");
+    DISPATCH(dtype, fn,
+             misc_residual<float>((const float*)y_dev, (const float*)fbar_dev, (const float*)bias_dev, n, q, (float*)r_dev,
+                                  S(stream)),
+             misc_residual<double>((const double*)y_dev, (const double*)fbar_dev, (const double*)bias_dev, n, q,
+                                   (double*)r_dev, S(stream)));
+}
+
+int cimrgp_train_mean(int dtype, const void* r_dev, const void* alpha_dev, const void* bias_dev, const void* noise_dev,
+                      int64_t n, int q, void* out_dev, int accumulate, void* stream)
+{
+    const char* fn = "cimrgp_train_mean";
+    CIMRGP_REQUIRE(r_dev && alpha_dev && noise_dev && out_dev, fn, "null pointer");
+    DISPATCH(dtype, fn,
+             misc_train_mean<float>((const float*)r_dev, (const float*)alpha_dev, (const float*)bias_dev,
+                                    (const float*)noise_dev, n, q, (float*)out_dev, accumulate, S(stream)),
+             misc_train_mean<double>((const double*)r_dev, (const double*)alpha_dev, (const double*)bias_dev,
+                                     (const double*)noise_dev, n, q, (double*)out_dev, accumulate, S(stream)));
+}
+
+int cimrgp_add_diag(int dtype, void* k_dev, int64_t n, int64_t ldk, const void* noise_dev, void* stream)
+{
+    const char* fn = "cimrgp_add_diag";
+    CIMRGP_REQUIRE(k_dev && noise_dev, fn, "null pointer");
+    DISPATCH(dtype, fn,
+             misc_add_diag<float>((float*)k_dev, n, ldk, (const float*)noise_dev, S(stream)),
+             misc_add_diag<double>((double*)k_dev, n, ldk, (const double*)noise_dev, S(stream)));
+}
+
+int cimrgp_noise_from_stats(int dtype, const void* stats_dev, int q, double frac, double floor_value, void* noise_dev,
+                            void* stream)
+{
+    const char* fn = "cimrgp_noise_from_stats";
+    CIMRGP_REQUIRE(stats_dev && noise_dev, fn, "null pointer");
+    DISPATCH(dtype, fn,
+             misc_noise_from_stats<float>((const float*)stats_dev, q, frac, floor_value, (float*)noise_dev, S(stream)),
+             misc_noise_from_stats<double>((const double*)stats_dev, q, frac, floor_value, (double*)noise_dev, S(stream)));
+}
+
+int cimrgp_logdet_half(int dtype, const void* l_dev, int64_t n, int64_t ldl, double* out_dev, void* stream)
+{
+    const char* fn = "cimrgp_logdet_half";
+    CIMRGP_REQUIRE(l_dev && out_dev, fn, "null pointer");
+    DISPATCH(dtype, fn,
+             misc_logdet_half<float>((const float*)l_dev, n, ldl, out_dev, S(stream)),
+             misc_logdet_half<double>((const double*)l_dev, n, ldl, out_dev, S(stream)));
+}
+
+int cimrgp_profile_begin(void) { return profile_begin(); }
+
+int cimrgp_profile_collect(double* total_ms, double* total_flops, int64_t* launches)
+{
+    return profile_collect(total_ms, total_flops, launches);
+}
+
+}  // extern "C"

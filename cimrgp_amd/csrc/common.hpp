@@ -1,0 +1,113 @@
+// Shared device/host helpers for the gfx950 dense-GP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/cimrgp.h"
+
+namespace cimrgp {
+
+// ---------------------------------------------------------------- errors ----
+void set_error(const std::string& msg);
+int  fail(const char* fn, const char* what);
+int  check_hip(hipError_t e, const char* fn, const char* what);
+
+#define CIMRGP_REQUIRE(cond, fn, what) \
+    do { if (!(cond)) return ::cimrgp::fail(fn, what); } while (0)
+#define CIMRGP_LAUNCH_CHECK(fn) \
+    do { hipError_t e__ = hipGetLastError(); \
+         if (e__ != hipSuccess) return ::cimrgp::check_hip(e__, fn, "kernel launch"); } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ------------------------------------------------------------ MFMA traits ----
+// 16x16x4 matrix-core tiles, one 8-byte "k-slot" per lane per operand:
+//   lane l supplies A[row = l & 15][kslot = l >> 4] and B^T[col = l & 15][kslot = l >> 4].
+// f64: a slot is one double  -> one v_mfma_f64_16x16x4_f64.
+// f32: a slot is two floats  -> two v_mfma_f32_16x16x4_f32 (k order inside the
+//      slot is irrelevant because A and B use the same slot->k map).
+template <typename T> struct Mx;
+
+template <> struct Mx<double> {
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    static constexpr int EPC = 2;     // elements per 16-byte chunk
+    static constexpr int EPS = 1;     // elements per 8-byte k-slot
+    // C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 r
+    static __device__ __forceinline__ int crow(int lane, int r) { return (lane >> 4) + 4 * r; }
+    static __device__ __forceinline__ acc_t mma(uint2 a, uint2 b, acc_t c) {
+        double da = __hiloint2double((int)a.y, (int)a.x);
+        double db = __hiloint2double((int)b.y, (int)b.x);
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(da, db, c, 0, 0, 0);
+    }
+};
+
+template <> struct Mx<float> {
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    static constexpr int EPC = 4;
+    static constexpr int EPS = 2;
+    // C/D map of v_mfma_f32_16x16x4_f32: col = lane & 15, row = 4 (lane >> 4) + r
+    static __device__ __forceinline__ int crow(int lane, int r) { return 4 * (lane >> 4) + r; }
+    static __device__ __forceinline__ acc_t mma(uint2 a, uint2 b, acc_t c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+        return c;
+    }
+};
+
+template <typename T>
+static __device__ __forceinline__ typename Mx<T>::acc_t acc_zero() {
+    typename Mx<T>::acc_t z = {0, 0, 0, 0};
+    return z;
+}
+
+// Zero the elements of a 16-byte chunk whose k index is >= kvalid.
+template <typename T>
+static __device__ __forceinline__ uint4 mask_chunk(uint4 v, int kfirst, int kvalid);
+template <>
+__device__ __forceinline__ uint4 mask_chunk<double>(uint4 v, int kfirst, int kvalid) {
+    if (kfirst     >= kvalid) { v.x = 0; v.y = 0; }
+    if (kfirst + 1 >= kvalid) { v.z = 0; v.w = 0; }
+    return v;
+}
+template <>
+__device__ __forceinline__ uint4 mask_chunk<float>(uint4 v, int kfirst, int kvalid) {
+    if (kfirst     >= kvalid) v.x = 0;
+    if (kfirst + 1 >= kvalid) v.y = 0;
+    if (kfirst + 2 >= kvalid) v.z = 0;
+    if (kfirst + 3 >= kvalid) v.w = 0;
+    return v;
+}
+
+// --------------------------------------------------------- host launchers ----
+// potrf.hip
+template <typename T> int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, hipStream_t st);
+template <typename T> int solve_rows_run(const T* l, int64_t n, int64_t ld, const T* ws, T* b, int64_t m,
+                                         int64_t ldb, hipStream_t st);
+int profile_begin();
+int profile_collect(double* total_ms, double* total_flops, int64_t* launches);
+// gemm_nt.hip
+template <typename T> int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t ldb,
+                                      int64_t m, int64_t n, int k, bool lower, hipStream_t st);
+
+// gram.hip
+template <typename T> int rbf_gram_run(const T* xa, int64_t na, const T* xb, int64_t nb, int d, double ell, double sf2,
+                                       double diag_add, T* k, int64_t ld, bool symm, bool lower_only, hipStream_t st);
+template <typename T> int predict_mean_run(const T* x, int64_t n, int d, const T* alpha, int q, const T* xs, int64_t ns,
+                                           double ell, double sf2, const T* bias, T* mean, int accumulate, hipStream_t st);
+// solve.hip
+template <typename T> int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* z_out, T* scratch,
+                                    hipStream_t st);
+template <typename T> int predict_from_w_run(const T* w, int64_t ns, int64_t n, int64_t ldw, const T* z, int q, double sf2,
+                                             double extra, const T* bias, T* mean, T* var, int accumulate, hipStream_t st);
+// misc.hip
+template <typename T> int misc_block_stats(const T* y, const T* fbar, int64_t n, int q, T* stats, hipStream_t st);
+template <typename T> int misc_residual(const T* y, const T* fbar, const T* bias, int64_t n, int q, T* r, hipStream_t st);
+template <typename T> int misc_train_mean(const T* r, const T* alpha, const T* bias, const T* noise, int64_t n, int q,
+                                          T* out, int accumulate, hipStream_t st);
+template <typename T> int misc_add_diag(T* k, int64_t n, int64_t ld, const T* noise, hipStream_t st);
+template <typename T> int misc_noise_from_stats(const T* stats, int q, double frac, double floor_value, T* noise, hipStream_t st);
+template <typename T> int misc_logdet_half(const T* l, int64_t n, int64_t ld, double* out, hipStream_t st);
+
+}  // namespace cimrgp

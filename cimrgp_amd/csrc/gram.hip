@@ -1,0 +1,214 @@
+// D1: tiled RBF Gram / cross-Gram builder and D4: fused predictive mean.
+//
+// Gram: one workgroup = one 64 x 64 tile; the row and column input tiles are
+// staged in LDS once; each thread produces a 4 x 4 patch whose 4 columns are
+// contiguous, so a 16-lane row group stores 16 x 32 B (f64) = 512 contiguous
+// bytes per matrix row.  HBM-write bound: n^2 * sizeof(T) bytes,
+// with the exp as the secondary limiter in f64.
+#include "common.hpp"
+
+namespace cimrgp {
+
+namespace {
+
+constexpr int GTILE = 64;
+constexpr int MAXD  = 8;
+
+// D = compile-time input dimension (1, 2) or 0 = run-time d <= 8 with fully
+// unrolled, predicated loops (run-time indexed register arrays would spill).
+template <typename T, bool SYMM, int D>
+__global__ __launch_bounds__(256)
+void k_rbf_gram(const T* __restrict__ xa, int na, const T* __restrict__ xb, int nb, int d,
+                T neg_half_inv_l2, T sf2, T diag_add, T* __restrict__ K, int64_t ld,
+                int tiles_n, int lower_only)
+{
+    __shared__ T sa[GTILE * MAXD];
+    __shared__ T sb[GTILE * MAXD];
+    int ti, tj;
+    if (SYMM && lower_only) {
+        const int id = blockIdx.x;
+        ti = (int)((sqrtf(8.0f * (float)id + 1.0f) - 1.0f) * 0.5f);
+        while (ti * (ti + 1) / 2 > id) --ti;
+        while ((ti + 1) * (ti + 2) / 2 <= id) ++ti;
+        tj = id - ti * (ti + 1) / 2;
+    } else {
+        ti = blockIdx.x / tiles_n;
+        tj = blockIdx.x - ti * tiles_n;
+    }
+    const int row0 = ti * GTILE, col0 = tj * GTILE;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < GTILE * MAXD; e += 256) {
+        const int r = e / MAXD, k = e - r * MAXD;
+        sa[e] = (k < d && row0 + r < na) ? xa[(int64_t)(row0 + r) * d + k] : (T)0;
+        sb[e] = (k < d && col0 + r < nb) ? xb[(int64_t)(col0 + r) * d + k] : (T)0;
+    }
+    __syncthreads();
+
+    const int tx = tid & 15, ty = tid >> 4;     // tx: 4-column group, ty: row within a 16-row slab
+    constexpr int DD = D ? D : MAXD;
+    T xc[4][DD];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int k = 0; k < DD; ++k) xc[b][k] = sb[(tx * 4 + b) * MAXD + k];
+
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int r  = ty + 16 * a;
+        const int gr = row0 + r;
+        if (gr >= na) continue;
+        T out[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            T d2 = (T)0;
+#pragma unroll
+            for (int k = 0; k < DD; ++k) {
+                if (D || k < d) {
+                    const T df = sa[r * MAXD + k] - xc[b][k];
+                    d2 += df * df;
+                }
+            }
+            T v = sf2 * exp(d2 * neg_half_inv_l2);
+            if (SYMM && (gr == col0 + tx * 4 + b)) v += diag_add;
+            out[b] = v;
+        }
+        const int gc = col0 + tx * 4;
+        T* dst = K + (int64_t)gr * ld + gc;
+        if (gc + 3 < nb && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) {
+            if (sizeof(T) == 8) {
+                reinterpret_cast<double2*>(dst)[0] = make_double2((double)out[0], (double)out[1]);
+                reinterpret_cast<double2*>(dst)[1] = make_double2((double)out[2], (double)out[3]);
+            } else {
+                *reinterpret_cast<float4*>(dst) = make_float4((float)out[0], (float)out[1], (float)out[2], (float)out[3]);
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (gc + b < nb) dst[b] = out[b];
+        }
+    }
+}
+
+// D4: mean[i][c] (+)= bias[c] + sum_j k(xs_i, x_j) alpha[j][c].
+// Workgroup = 8 test points x 32 partial sums over the training points; the
+// cross-Gram row is never written anywhere.  Deterministic (fixed-order LDS
+// reduction, no atomics).
+constexpr int PM_TS = 8;
+constexpr int PM_PH = 32;
+constexpr int MAXQ  = 8;
+
+template <typename T, int D>
+__global__ __launch_bounds__(256)
+void k_predict_mean(const T* __restrict__ x, int n, int d, const T* __restrict__ alpha, int q,
+                    const T* __restrict__ xs, int ns, T neg_half_inv_l2, T sf2,
+                    const T* __restrict__ bias, T* __restrict__ mean, int accumulate)
+{
+    __shared__ T red[PM_PH][PM_TS][MAXQ];
+    const int tid = threadIdx.x;
+    const int t  = tid & (PM_TS - 1);
+    const int ph = tid / PM_TS;
+    const int gi = blockIdx.x * PM_TS + t;
+    constexpr int DD = D ? D : MAXD;
+    T xt[DD];
+#pragma unroll
+    for (int k = 0; k < DD; ++k) xt[k] = ((D || k < d) && gi < ns) ? xs[(int64_t)gi * d + k] : (T)0;
+    T sum[MAXQ];
+#pragma unroll
+    for (int c = 0; c < MAXQ; ++c) sum[c] = (T)0;
+    for (int j = ph; j < n; j += PM_PH) {
+        T d2 = (T)0;
+#pragma unroll
+        for (int k = 0; k < DD; ++k) {
+            if (D || k < d) {
+                const T df = xt[k] - x[(int64_t)j * d + k];
+                d2 += df * df;
+            }
+        }
+        const T kv = sf2 * exp(d2 * neg_half_inv_l2);
+#pragma unroll
+        for (int c = 0; c < MAXQ; ++c)
+            if (c < q) sum[c] += kv * alpha[(int64_t)j * q + c];
+    }
+#pragma unroll
+    for (int c = 0; c < MAXQ; ++c) red[ph][t][c] = sum[c];
+    __syncthreads();
+    if (tid < PM_TS * q) {
+        const int tt = tid / q, c = tid - tt * q;
+        const int g = blockIdx.x * PM_TS + tt;
+        if (g < ns) {
+            T s = bias ? bias[c] : (T)0;
+            for (int p = 0; p < PM_PH; ++p) s += red[p][tt][c];
+            T* o = mean + (int64_t)g * q + c;
+            *o = accumulate ? (*o + s) : s;
+        }
+    }
+}
+
+}  // namespace
+
+template <typename T>
+int rbf_gram_run(const T* xa, int64_t na, const T* xb, int64_t nb, int d, double ell, double sf2,
+                 double diag_add, T* k, int64_t ld, bool symm, bool lower_only, hipStream_t st)
+{
+    const char* fn = symm ? "cimrgp_rbf_gram" : "cimrgp_rbf_cross";
+    if (na <= 0 || nb <= 0) return 0;
+    CIMRGP_REQUIRE(d >= 1 && d <= MAXD, fn, "input dimension must be in [1, 8]");
+    CIMRGP_REQUIRE(ell > 0.0, fn, "length-scale must be positive");
+    CIMRGP_REQUIRE(ld >= nb, fn, "leading dimension smaller than the number of columns");
+    CIMRGP_REQUIRE(na < (1ll << 30) && nb < (1ll << 30), fn, "matrix too large");
+    const int64_t tm = (na + GTILE - 1) / GTILE, tn = (nb + GTILE - 1) / GTILE;
+    const T c = (T)(-0.5 / (ell * ell));
+#define CIMRGP_GRAM_LAUNCH(SYMM_, D_, tiles_, diag_, lo_)                                   \
+    hipLaunchKernelGGL((k_rbf_gram<T, SYMM_, D_>), dim3((unsigned)(tiles_)), dim3(256), 0, st, \
+                       xa, (int)na, xb, (int)nb, d, c, (T)sf2, (T)(diag_), k, ld, (int)tn, (lo_))
+    if (symm) {
+        const int64_t tiles = lower_only ? tm * (tm + 1) / 2 : tm * tn;
+        CIMRGP_REQUIRE(tiles < (1ll << 31), fn, "grid too large");
+        const int lo = lower_only ? 1 : 0;
+        if (d == 1)      CIMRGP_GRAM_LAUNCH(true, 1, tiles, diag_add, lo);
+        else if (d == 2) CIMRGP_GRAM_LAUNCH(true, 2, tiles, diag_add, lo);
+        else             CIMRGP_GRAM_LAUNCH(true, 0, tiles, diag_add, lo);
+    } else {
+        const int64_t tiles = tm * tn;
+        CIMRGP_REQUIRE(tiles < (1ll << 31), fn, "grid too large");
+        if (d == 1)      CIMRGP_GRAM_LAUNCH(false, 1, tiles, 0, 0);
+        else if (d == 2) CIMRGP_GRAM_LAUNCH(false, 2, tiles, 0, 0);
+        else             CIMRGP_GRAM_LAUNCH(false, 0, tiles, 0, 0);
+    }
+#undef CIMRGP_GRAM_LAUNCH
+    CIMRGP_LAUNCH_CHECK(fn);
+    return 0;
+}
+
+template <typename T>
+int predict_mean_run(const T* x, int64_t n, int d, const T* alpha, int q, const T* xs, int64_t ns,
+                     double ell, double sf2, const T* bias, T* mean, int accumulate, hipStream_t st)
+{
+    const char* fn = "cimrgp_predict_mean";
+    if (ns <= 0) return 0;
+    CIMRGP_REQUIRE(d >= 1 && d <= MAXD, fn, "input dimension must be in [1, 8]");
+    CIMRGP_REQUIRE(q >= 1 && q <= MAXQ, fn, "number of outputs must be in [1, 8]");
+    CIMRGP_REQUIRE(ell > 0.0, fn, "length-scale must be positive");
+    CIMRGP_REQUIRE(n < (1ll << 31) && ns < (1ll << 31), fn, "too many points");
+    const unsigned grid = (unsigned)((ns + PM_TS - 1) / PM_TS);
+#define CIMRGP_PM_LAUNCH(D_)                                                              \
+    hipLaunchKernelGGL((k_predict_mean<T, D_>), dim3(grid), dim3(256), 0, st, x, (int)n, d, \
+                       alpha, q, xs, (int)ns, (T)(-0.5 / (ell * ell)), (T)sf2, bias, mean, accumulate)
+    if (d == 1)      CIMRGP_PM_LAUNCH(1);
+    else if (d == 2) CIMRGP_PM_LAUNCH(2);
+    else             CIMRGP_PM_LAUNCH(0);
+#undef CIMRGP_PM_LAUNCH
+    CIMRGP_LAUNCH_CHECK(fn);
+    return 0;
+}
+
+template int rbf_gram_run<double>(const double*, int64_t, const double*, int64_t, int, double, double, double,
+                                  double*, int64_t, bool, bool, hipStream_t);
+template int rbf_gram_run<float>(const float*, int64_t, const float*, int64_t, int, double, double, double,
+                                 float*, int64_t, bool, bool, hipStream_t);
+template int predict_mean_run<double>(const double*, int64_t, int, const double*, int, const double*, int64_t,
+                                      double, double, const double*, double*, int, hipStream_t);
+template int predict_mean_run<float>(const float*, int64_t, int, const float*, int, const float*, int64_t,
+                                     double, double, const float*, float*, int, hipStream_t);
+
+}  // namespace cimrgp

@@ -1,0 +1,204 @@
+"""Thin, typed wrappers around the C ABI operating on torch CUDA tensors.
+
+torch is used for device memory, streams and (elsewhere) torch.distributed --
+plumbing only; every arithmetic operation of the path below is a hand-written
+HIP kernel reached through ``libcimrgp.so``.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: _lib.F32, torch.float64: _lib.F64}
+
+
+def as_torch_dtype(dtype):
+    if isinstance(dtype, torch.dtype):
+        if dtype not in _DT:
+            raise ValueError("dtype must be float32 or float64")
+        return dtype
+    key = str(dtype).lower()
+    if key in ("f64", "float64", "fp64", "double", "<class 'numpy.float64'>"):
+        return torch.float64
+    if key in ("f32", "float32", "fp32", "float", "<class 'numpy.float32'>"):
+        return torch.float32
+    raise ValueError("dtype must be 'f32' or 'f64', got %r" % (dtype,))
+
+
+def require_gpu(device=None):
+    """Resolve the device of the product path; there is no CPU fallback."""
+    _lib.load()
+    if not torch.cuda.is_available():
+        raise RuntimeError("cimrgp_amd: no HIP device visible; the dense GP path has no CPU fallback "
+                           "(the NumPy restatement under oracle/ is test infrastructure only)")
+    if device is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device(device)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def padded_ld(n):
+    """Row pitch (elements): multiple of 16 so every row starts on a 128-byte line."""
+    return max(16, (int(n) + 15) // 16 * 16)
+
+
+def alloc_matrix(rows, cols, dtype, device):
+    """(rows x cols) row-major view of a buffer with a padded leading dimension."""
+    ld = padded_ld(cols)
+    buf = torch.empty((max(int(rows), 1), ld), dtype=dtype, device=device)
+    return buf
+
+
+def to_device(a, dtype, device):
+    t = torch.as_tensor(np.ascontiguousarray(a)) if not isinstance(a, torch.Tensor) else a
+    return t.to(device=device, dtype=dtype).contiguous()
+
+
+def rbf_gram(x, ell, sf2, diag_add=0.0, lower_only=False, out=None):
+    """D1.  x: (n x d) device tensor.  Returns the (n x ld) buffer; [:, :n] is K."""
+    n, d = x.shape
+    if out is None:
+        out = alloc_matrix(n, n, x.dtype, x.device)
+    lib = _lib.load()
+    _lib.check(lib.cimrgp_rbf_gram(_DT[x.dtype], _p(x), n, d, float(ell), float(sf2), float(diag_add),
+                                   _p(out), out.stride(0), int(bool(lower_only)), _stream()), "cimrgp_rbf_gram")
+    return out
+
+
+def rbf_cross(xa, xb, ell, sf2, out=None):
+    """Cross-Gram (na x nb) into a padded buffer."""
+    na, d = xa.shape
+    nb = xb.shape[0]
+    if out is None:
+        out = alloc_matrix(na, nb, xa.dtype, xa.device)
+    lib = _lib.load()
+    _lib.check(lib.cimrgp_rbf_cross(_DT[xa.dtype], _p(xa), na, _p(xb), nb, d, float(ell), float(sf2),
+                                    _p(out), out.stride(0), _stream()), "cimrgp_rbf_cross")
+    return out
+
+
+def potrf_workspace(n, dtype, device):
+    lib = _lib.load()
+    nbytes = lib.cimrgp_potrf_workspace_bytes(_DT[dtype], int(n))
+    return torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
+
+
+def potrf(kbuf, n, ws=None, info=None):
+    """D2 in place on kbuf[:n, :n] (lower).  Returns (ws, info) -- info is a
+    device int32 scalar written asynchronously (LAPACK convention)."""
+    lib = _lib.load()
+    if ws is None:
+        ws = potrf_workspace(n, kbuf.dtype, kbuf.device)
+    if info is None:
+        info = torch.zeros(1, dtype=torch.int32, device=kbuf.device)
+    _lib.check(lib.cimrgp_potrf(_DT[kbuf.dtype], _p(kbuf), int(n), kbuf.stride(0), _p(ws), ws.numel(),
+                                _p(info), _stream()), "cimrgp_potrf")
+    return ws, info
+
+
+def raise_if_not_pd(info):
+    """LinAlgError is the exception the reference's PD guard keys on
+    (SanityCheck.py:59-65)."""
+    code = int(info.item()) if isinstance(info, torch.Tensor) else int(info)
+    if code != 0:
+        raise np.linalg.LinAlgError("Matrix is not positive definite (leading minor of order %d)" % code)
+
+
+def potrs(lbuf, n, ws, rhs, want_z=False):
+    """D3: rhs (n x q) is overwritten with alpha.  Returns z = L^-1 rhs if asked."""
+    lib = _lib.load()
+    q = rhs.shape[1]
+    scratch = torch.empty(2 * q * max(int(n), 1), dtype=lbuf.dtype, device=lbuf.device)
+    z = torch.empty_like(rhs) if want_z else None
+    _lib.check(lib.cimrgp_potrs(_DT[lbuf.dtype], _p(lbuf), int(n), lbuf.stride(0), _p(ws), _p(rhs), q,
+                                _p(z), _p(scratch), _stream()), "cimrgp_potrs")
+    return z
+
+
+def trsm_rows(lbuf, n, ws, bbuf, m):
+    """B <- B L^-T on bbuf[:m, :n]."""
+    lib = _lib.load()
+    _lib.check(lib.cimrgp_trsm_rows(_DT[lbuf.dtype], _p(lbuf), int(n), lbuf.stride(0), _p(ws), _p(bbuf),
+                                    int(m), bbuf.stride(0), _stream()), "cimrgp_trsm_rows")
+    return bbuf
+
+
+def predict_mean(x, alpha, xs, ell, sf2, bias=None, out=None, accumulate=False):
+    """D4 fused mean: out (ns x q) (+)= bias + K(xs, x) alpha."""
+    lib = _lib.load()
+    n, d = x.shape
+    ns = xs.shape[0]
+    q = alpha.shape[1]
+    if out is None:
+        out = torch.empty((ns, q), dtype=x.dtype, device=x.device)
+        accumulate = False
+    _lib.check(lib.cimrgp_predict_mean(_DT[x.dtype], _p(x), n, d, _p(alpha), q, _p(xs), ns, float(ell),
+                                       float(sf2), _p(bias), _p(out), int(bool(accumulate)), _stream()),
+               "cimrgp_predict_mean")
+    return out
+
+
+def predict_from_w(wbuf, ns, n, z, sf2, extra_var=0.0, bias=None, mean_out=None, var_out=None, accumulate=False):
+    lib = _lib.load()
+    q = 0 if z is None else z.shape[1]
+    _lib.check(lib.cimrgp_predict_from_w(_DT[wbuf.dtype], _p(wbuf), int(ns), int(n), wbuf.stride(0), _p(z), q,
+                                         float(sf2), float(extra_var), _p(bias), _p(mean_out), _p(var_out),
+                                         int(bool(accumulate)), _stream()), "cimrgp_predict_from_w")
+
+
+def block_stats(y, fbar, stats_out=None):
+    lib = _lib.load()
+    n, q = y.shape
+    if stats_out is None:
+        stats_out = torch.empty(q + 1, dtype=y.dtype, device=y.device)
+    _lib.check(lib.cimrgp_block_stats(_DT[y.dtype], _p(y), _p(fbar), n, q, _p(stats_out), _stream()),
+               "cimrgp_block_stats")
+    return stats_out
+
+
+def residual(y, fbar, bias, out=None):
+    lib = _lib.load()
+    n, q = y.shape
+    if out is None:
+        out = torch.empty_like(y)
+    _lib.check(lib.cimrgp_residual(_DT[y.dtype], _p(y), _p(fbar), _p(bias), n, q, _p(out), _stream()),
+               "cimrgp_residual")
+    return out
+
+
+def train_mean(r, alpha, bias, noise, out, accumulate=False):
+    lib = _lib.load()
+    n, q = r.shape
+    _lib.check(lib.cimrgp_train_mean(_DT[r.dtype], _p(r), _p(alpha), _p(bias), _p(noise), n, q, _p(out),
+                                     int(bool(accumulate)), _stream()), "cimrgp_train_mean")
+    return out
+
+
+def add_diag(kbuf, n, noise):
+    lib = _lib.load()
+    _lib.check(lib.cimrgp_add_diag(_DT[kbuf.dtype], _p(kbuf), int(n), kbuf.stride(0), _p(noise), _stream()),
+               "cimrgp_add_diag")
+
+
+def noise_from_stats(stats, q, frac, floor_value, out=None):
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(1, dtype=stats.dtype, device=stats.device)
+    _lib.check(lib.cimrgp_noise_from_stats(_DT[stats.dtype], _p(stats), int(q), float(frac), float(floor_value),
+                                           _p(out), _stream()), "cimrgp_noise_from_stats")
+    return out
+
+
+def logdet_half(lbuf, n):
+    lib = _lib.load()
+    out = torch.empty(1, dtype=torch.float64, device=lbuf.device)
+    _lib.check(lib.cimrgp_logdet_half(_DT[lbuf.dtype], _p(lbuf), int(n), lbuf.stride(0), _p(out), _stream()),
+               "cimrgp_logdet_half")
+    return out

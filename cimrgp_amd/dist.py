@@ -1,0 +1,47 @@
+"""Sharding of the independent (resolution, region) blocks over the GPUs of a node.
+
+One process per GPU (``torch.distributed``; backend "nccl" is RCCL on ROCm,
+"gloo" in the CPU tests).  Blocks of one layer are independent; layers form a
+short chain through the residual f_bar (Stats.py:126-157).  Communication:
+  * fit: one all-reduce per layer of the layer's training-point prediction
+    (N x q, disjoint slices summed) so every rank holds f_bar for the next layer;
+  * predict: ONE all-reduce of the fused [mean | var] buffer (N* x (q+1)) --
+    the sum over resolutions of MRGP.py:802-803.
+Payloads are a few MiB: latency-bound on xGMI, so a single fused buffer per
+exchange and no bucketing.
+"""
+import numpy as np
+import torch
+import torch.distributed as td
+
+
+def world(group=None):
+    """(rank, world_size) of ``group``; (0, 1) when torch.distributed is not initialised."""
+    if td.is_available() and td.is_initialized():
+        return td.get_rank(group), td.get_world_size(group)
+    return 0, 1
+
+
+def assign_blocks(sizes, world_size):
+    """Longest-processing-time assignment of one layer's blocks to ranks.
+
+    ``sizes``: block lengths n_l; cost model n^3 (the Cholesky).  Deterministic:
+    ties are broken by region id, then by rank id, so every rank computes the
+    same map without communication.  Returns an int array owner[l]."""
+    sizes = np.asarray(sizes, dtype=np.float64)
+    order = sorted(range(len(sizes)), key=lambda l: (-sizes[l], l))
+    load = np.zeros(world_size)
+    owner = np.zeros(len(sizes), dtype=np.int64)
+    for l in order:
+        r = int(np.argmin(load))       # first minimum -> lowest rank id on ties
+        owner[l] = r
+        load[r] += sizes[l] ** 3
+    return owner
+
+
+def allreduce_sum_(tensor, group=None):
+    """In-place sum over ranks; a no-op for a single process."""
+    _, ws = world(group)
+    if ws > 1:
+        td.all_reduce(tensor, op=td.ReduceOp.SUM, group=group)
+    return tensor

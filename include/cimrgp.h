@@ -1,0 +1,158 @@
+/*
+ * cimrgp.h -- C ABI of the MI355X (gfx950) dense GP covariance/posterior path.
+ *
+ * This library replaces, for one (resolution, partition) block, the exact
+ * RBF Gaussian-process arithmetic that the reference reaches only through its
+ * `RegressionMethod.fit/predict` plugin (src/RegressionInput.py:10-67, class
+ * GP_RBF -> third-party GPy) and the per-resolution residual combine of
+ * src/Stats.py:126-157 / src/MRGP.py:782-803.  The reference is pure Python;
+ * the binding a maintainer adds is a ctypes stub.
+ *
+ * Conventions
+ *  - Every pointer named *_dev is a DEVICE pointer (hipMalloc'd or a
+ *    torch.cuda tensor's data_ptr()); `stream` is a hipStream_t passed as
+ *    void* (NULL = the null stream).  Calls enqueue work and return; nothing
+ *    here synchronises, allocates or frees device memory (graph-capturable).
+ *  - Matrices are ROW-MAJOR with an explicit leading dimension in elements.
+ *    A symmetric matrix uses its LOWER triangle (row i, column j <= i); the
+ *    strictly upper triangle is never read and, after potrf, holds junk.
+ *  - dtype: CIMRGP_F32 or CIMRGP_F64 selects the element type of every
+ *    matrix/vector argument of that call.  Hyper-parameters are doubles.
+ *  - Return value: 0 = enqueued; <0 = argument / runtime error, message via
+ *    cimrgp_last_error().  Numerical failure of the factorisation is reported
+ *    asynchronously in *info_dev (LAPACK convention: 0 = ok, i > 0 = leading
+ *    minor of order i not positive definite; the Python wrapper raises
+ *    numpy.linalg.LinAlgError, the exception SanityCheck.py:59-65 keys on).
+ */
+#ifndef CIMRGP_H
+#define CIMRGP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { CIMRGP_F32 = 0, CIMRGP_F64 = 1 };
+
+/* Outer block size of the factorisation (columns per panel).  Diagonal-block
+ * inverses are kept in the workspace in slabs of CIMRGP_NB x CIMRGP_NB. */
+#define CIMRGP_NB 256
+
+int         cimrgp_version(void);
+const char* cimrgp_last_error(void);
+/* Number of visible HIP devices (does not create a context). */
+int         cimrgp_device_count(void);
+
+/* ---- D1: RBF Gram builder --------------------------------------------------
+ * Replaces GPy.kern.RBF(d, ARD=False).K(X) behind RegressionInput.py:60-61.
+ *   K[a][b] = sf2 * exp(-|x_a - x_b|^2 / (2 ell^2)) + (a == b ? diag_add : 0)
+ * x_dev: (n x d) row-major.  lower_only != 0 writes only tiles that touch the
+ * lower triangle.  d <= 8. */
+int cimrgp_rbf_gram(int dtype, const void* x_dev, int64_t n, int d,
+                    double ell, double sf2, double diag_add,
+                    void* k_dev, int64_t ldk, int lower_only, void* stream);
+
+/* Cross-Gram  Kab[a][b] = k(xa_a, xb_b),  (na x nb) row-major, ld >= nb.
+ * Replaces kern.K(X*, X) inside GPy's predict (RegressionInput.py:66-67). */
+int cimrgp_rbf_cross(int dtype, const void* xa_dev, int64_t na,
+                     const void* xb_dev, int64_t nb, int d,
+                     double ell, double sf2,
+                     void* kab_dev, int64_t ld, void* stream);
+
+/* ---- D2: blocked in-place Cholesky  K = L L^T (lower) ----------------------
+ * Replaces the Cholesky inside GPy's exact-Gaussian inference
+ * (RegressionInput.py:61-63).  Right-looking, panel width CIMRGP_NB:
+ * diagonal-block factor + inverse (one workgroup, MFMA inside), panel solve
+ * as a product with the inverted diagonal block (MFMA), trailing SYRK/GEMM
+ * update (MFMA 16x16x4 f64 / f32).
+ * workspace: cimrgp_potrf_workspace_bytes(dtype, n) bytes, keeps the inverted
+ * diagonal blocks needed by cimrgp_potrs / cimrgp_trsm_rows afterwards.
+ * info_dev: one int32, written asynchronously. */
+size_t cimrgp_potrf_workspace_bytes(int dtype, int64_t n);
+int cimrgp_potrf(int dtype, void* k_dev, int64_t n, int64_t ldk,
+                 void* workspace_dev, size_t workspace_bytes,
+                 int32_t* info_dev, void* stream);
+
+/* ---- D3: alpha = (L L^T)^-1 R  for q right-hand sides ---------------------
+ * Replaces the two triangular solves of GPy's posterior ("woodbury vector").
+ * rhs_dev: (n x q) row-major, overwritten with alpha.  z_dev (optional, may
+ * be NULL): (n x q) receives z = L^-1 R.  q <= 8.
+ * scratch_dev: 2*q*n elements of dtype. */
+int cimrgp_potrs(int dtype, const void* l_dev, int64_t n, int64_t ldl,
+                 const void* workspace_dev, void* rhs_dev, int q,
+                 void* z_dev, void* scratch_dev, void* stream);
+
+/* Row-wise triangular solve with many right-hand sides (MFMA):
+ *   B <- B L^-T      B: (m x n) row-major, ldb >= n,  i.e. row i of B becomes
+ * L^-1 b_i.  Used for D5: B = K(X*, X) gives the rows whose squared norms are
+ * subtracted from sf2. */
+int cimrgp_trsm_rows(int dtype, const void* l_dev, int64_t n, int64_t ldl,
+                     const void* workspace_dev, void* b_dev, int64_t m,
+                     int64_t ldb, void* stream);
+
+/* ---- D4: fused predictive mean (cross-Gram never stored) ------------------
+ *   mean[i][c] (+)= bias[c] + sum_j k(xs_i, x_j) alpha[j][c]
+ * Replaces GPy's predict mean (RegressionInput.py:66-67) and the per-region
+ * prediction of MRGP.py:794-800.  alpha_dev (n x q), mean_dev (ns x q),
+ * bias_dev (q) or NULL.  accumulate != 0 adds to mean_dev (sum over
+ * resolutions, MRGP.py:803). */
+int cimrgp_predict_mean(int dtype, const void* x_dev, int64_t n, int d,
+                        const void* alpha_dev, int q,
+                        const void* xs_dev, int64_t ns,
+                        double ell, double sf2, const void* bias_dev,
+                        void* mean_dev, int accumulate, void* stream);
+
+/* ---- D5 tail: from W = K(X*,X) L^-T  (ns x n, after cimrgp_trsm_rows) ------
+ *   var[i]     (+)= sf2 + extra_var - sum_j W[i][j]^2
+ *   mean[i][c] (+)= bias[c] + sum_j W[i][j] z[j][c]        (if mean_dev)
+ * z_dev (n x q) = L^-1 R from cimrgp_potrs.  mean_dev/var_dev may be NULL. */
+int cimrgp_predict_from_w(int dtype, const void* w_dev, int64_t ns, int64_t n,
+                          int64_t ldw, const void* z_dev, int q,
+                          double sf2, double extra_var, const void* bias_dev,
+                          void* mean_dev, void* var_dev, int accumulate,
+                          void* stream);
+
+/* ---- D6 / a11: residual chain helpers (Stats.py:126-157, Posteriors.py:68) -
+ * Column means of (y - fbar) over rows [0, n):  bias[c], and the population
+ * variance of the centred block (all q columns pooled) -> stats_dev[q].
+ * stats_dev: q+1 elements. */
+int cimrgp_block_stats(int dtype, const void* y_dev, const void* fbar_dev,
+                       int64_t n, int q, void* stats_dev, void* stream);
+/* r[i][c] = y[i][c] - fbar[i][c] - bias[c]   (targets of one block) */
+int cimrgp_residual(int dtype, const void* y_dev, const void* fbar_dev,
+                    const void* bias_dev, int64_t n, int q, void* r_dev,
+                    void* stream);
+/* Training-point prediction without another kernel pass:
+ *   K alpha = r - noise * alpha;   out[i][c] (+)= r - noise*alpha + bias[c]
+ * noise is read from noise_dev[0] (device scalar of dtype). */
+int cimrgp_train_mean(int dtype, const void* r_dev, const void* alpha_dev,
+                      const void* bias_dev, const void* noise_dev, int64_t n,
+                      int q, void* out_dev, int accumulate, void* stream);
+/* Add a device scalar to the diagonal: K[i][i] += noise_dev[0]. */
+int cimrgp_add_diag(int dtype, void* k_dev, int64_t n, int64_t ldk,
+                    const void* noise_dev, void* stream);
+/* noise_dev[0] = max(frac * stats_dev[q], floor)  (RegressionInput.py:62) */
+int cimrgp_noise_from_stats(int dtype, const void* stats_dev, int q,
+                            double frac, double floor_value, void* noise_dev,
+                            void* stream);
+
+/* sum_i log L[i][i]  (for the log marginal likelihood; one element of dtype
+ * double written to out_dev regardless of dtype). */
+int cimrgp_logdet_half(int dtype, const void* l_dev, int64_t n, int64_t ldl,
+                       double* out_dev, void* stream);
+
+/* ---- measurement hooks (bench.py roofline; no reference counterpart) ---------
+ * Between begin and collect every lower-triangular trailing-update launch of
+ * cimrgp_potrf is bracketed by HIP events on its own stream.  collect waits
+ * for them and returns the summed kernel time (ms), the summed ALGORITHMIC
+ * flops (M (M+1) K per launch) and the number of launches.
+ * HOST pointers.  Not thread-safe; meant for one benchmarking thread. */
+int cimrgp_profile_begin(void);
+int cimrgp_profile_collect(double* total_ms, double* total_flops, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CIMRGP_H */

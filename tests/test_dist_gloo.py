@@ -1,0 +1,94 @@
+"""world_size-2 test of the N>1 path on CPU (gloo): block ownership map, the
+per-layer residual all-reduce and the single fused [mean | var] reduce.  The
+per-block arithmetic is the oracle here (tests may use it as the checker); the
+sharding and reduction code is the product's (cimrgp_amd.dist)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as td
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _problem():
+    import oracle
+    rng = np.random.default_rng(5)
+    n, ns = 256, 96
+    x = np.sort(rng.uniform(-1.7, 1.7, size=(n, 1)), axis=0)
+    y = np.hstack([np.sin(3 * x), np.cos(5 * x)]) + 0.1 * rng.normal(size=(n, 2))
+    xs = np.sort(rng.uniform(-1.7, 1.7, size=(ns, 1)), axis=0)
+    bounds = oracle.index_bounds_uniform(n, 2, 2)
+    tbounds = oracle.index_bounds_uniform(ns, 2, 2)
+    specs = [oracle.DenseLayerSpec(1.0 / 2 ** j, 1.0, None) for j in range(3)]
+    return x, y, xs, bounds, tbounds, specs
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import oracle
+    from cimrgp_amd import dist
+    td.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    x, y, xs, bounds, tbounds, specs = _problem()
+    r, w = dist.world()
+    assert (r, w) == (rank, world)
+    f_bar = np.zeros_like(y)
+    model = []
+    for j, layer in enumerate(bounds):
+        owner = dist.assign_blocks([b - a for a, b in layer], w)
+        layer_pred = torch.zeros(y.shape, dtype=torch.float64)
+        blocks = {}
+        for l, (a, b) in enumerate(layer):
+            if owner[l] != r:
+                continue
+            resid = (y - f_bar)[a:b]
+            bias = resid.mean(axis=0)
+            noise = oracle.mrgp._noise_from_targets(resid, specs[j])
+            fit = oracle.block_fit(x[a:b], resid - bias, specs[j].ell, specs[j].sf2, noise)
+            layer_pred[a:b] = torch.from_numpy(resid - bias - noise * fit["alpha"] + bias)
+            blocks[l] = dict(a=a, b=b, bias=bias, noise=noise, alpha=fit["alpha"], L=fit["L"])
+        dist.allreduce_sum_(layer_pred)                 # per-layer residual exchange
+        f_bar = f_bar + layer_pred.numpy()
+        model.append((owner, blocks))
+    fused = torch.zeros((3, xs.shape[0]), dtype=torch.float64)
+    for j, (owner, blocks) in enumerate(model):
+        for l, blk in blocks.items():
+            ta, tb = tbounds[j][l]
+            m, v = oracle.block_predict(x[blk["a"]:blk["b"]], blk, xs[ta:tb], specs[j].ell, specs[j].sf2, True)
+            fused[:2, ta:tb] += torch.from_numpy((m + blk["bias"]).T)
+            fused[2, ta:tb] += torch.from_numpy(v + (blk["noise"] if j == len(model) - 1 else 0.0))
+    dist.allreduce_sum_(fused)                          # ONE reduce for the sum over resolutions
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), f_bar=f_bar, fused=fused.numpy())
+    td.destroy_process_group()
+
+
+def test_two_rank_sharded_chain_matches_single_process(tmp_path):
+    import oracle
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    x, y, xs, bounds, tbounds, specs = _problem()
+    model, f_bar = oracle.mrgp_fit(x, y, bounds, specs)
+    mean, var = oracle.mrgp_predict(x, model, specs, xs, tbounds, True, True)
+    for rank in range(2):
+        g = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
+        np.testing.assert_allclose(g["f_bar"], f_bar, rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(g["fused"][:2].T, mean, rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(g["fused"][2], var, rtol=1e-10, atol=1e-13)
+
+
+def test_single_process_world_is_identity():
+    from cimrgp_amd import dist
+    assert dist.world() == (0, 1)
+    t = torch.arange(4.0)
+    assert dist.allreduce_sum_(t) is t

@@ -1,0 +1,228 @@
+"""Parity of every HIP kernel, called through the C ABI, with the FP64 oracle.
+
+Tolerances (relative to the largest reference magnitude of the array):
+  f64: 1e-10 for Gram/solves (blocked summation order differs from LAPACK),
+  f32: stated per test -- the f32 path is a precision sweep, not a parity claim.
+north_star's bar is 1e-5 relative on predictive mean / variance (f64 path).
+"""
+import os
+
+import numpy as np
+import pytest
+import scipy.linalg as sla
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from cimrgp_amd import device
+    device.require_gpu()
+    return device
+
+
+def _relerr(a, b):
+    return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - b)) / (np.max(np.abs(b)) + 1e-300))
+
+
+def _data(n, d, seed=0, q=2):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-1.7, 1.7, size=(n, d))
+    x = x[np.argsort(x[:, 0])]
+    y = np.stack([np.sin(3 * x[:, 0]) + 0.3 * x[:, -1], np.cos(2 * x[:, 0] * x[:, -1])] +
+                 [np.sin((c + 2) * x[:, 0]) for c in range(q - 2)], axis=1)
+    y += 0.05 * rng.normal(size=y.shape)
+    return x, y
+
+
+TDT = {"f64": "float64", "f32": "float32"}
+
+
+@pytest.mark.parametrize("dt,tol", [("f64", 1e-13), ("f32", 2e-6)])
+@pytest.mark.parametrize("n,d", [(1, 1), (63, 1), (64, 2), (65, 3), (257, 2), (1000, 1), (130, 8)])
+@pytest.mark.parametrize("lower_only", [False, True])
+def test_rbf_gram(dev, dt, tol, n, d, lower_only):
+    x, _ = _data(n, d, seed=n)
+    tdt = getattr(torch, TDT[dt])
+    xd = dev.to_device(x, tdt, "cuda")
+    buf = dev.rbf_gram(xd, 0.37, 1.9, 0.05, lower_only=lower_only)
+    k = buf[:n, :n].double().cpu().numpy()
+    ref = oracle.rbf_gram(x, None, 0.37, 1.9, 0.05)
+    if lower_only:
+        k, ref = np.tril(k), np.tril(ref)
+    assert _relerr(k, ref) < tol
+
+
+@pytest.mark.parametrize("dt,tol", [("f64", 1e-13), ("f32", 2e-6)])
+def test_rbf_cross_ragged(dev, dt, tol):
+    xa, _ = _data(77, 2, seed=1)
+    xb, _ = _data(201, 2, seed=2)
+    tdt = getattr(torch, TDT[dt])
+    buf = dev.rbf_cross(dev.to_device(xa, tdt, "cuda"), dev.to_device(xb, tdt, "cuda"), 0.8, 0.7)
+    assert _relerr(buf[:77, :201].double().cpu().numpy(), oracle.rbf_gram(xa, xb, 0.8, 0.7)) < tol
+
+
+def _factor(dev, x, ell, sf2, noise, tdt):
+    n = x.shape[0]
+    xd = dev.to_device(x, tdt, "cuda")
+    kbuf = dev.rbf_gram(xd, ell, sf2, noise, lower_only=True)
+    ws, info = dev.potrf(kbuf, n)
+    return xd, kbuf, ws, info
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 128, 191, 256, 257, 320, 511, 512, 700, 1025])
+def test_potrf_f64_matches_lapack(dev, n):
+    x, _ = _data(n, 1, seed=n)
+    ell, sf2, noise = 0.3, 1.0, 0.01
+    _, kbuf, ws, info = _factor(dev, x, ell, sf2, noise, torch.float64)
+    assert int(info.item()) == 0
+    lmat = np.tril(kbuf[:n, :n].cpu().numpy())
+    ref, rinfo = oracle.potrf_lower(oracle.rbf_gram(x, None, ell, sf2, noise))
+    assert rinfo == 0
+    assert _relerr(lmat, ref) < 1e-10
+    # the inverted 64x64 diagonal blocks left in the workspace
+    inv = ws.view(torch.float64).cpu().numpy().reshape(-1, 64, 64)
+    for s in range((n + 63) // 64):
+        w = min(64, n - 64 * s)
+        blk = ref[64 * s:64 * s + w, 64 * s:64 * s + w]
+        np.testing.assert_allclose(inv[s][:w, :w] @ blk, np.eye(w), atol=1e-9)
+        assert np.all(np.triu(inv[s], 1) == 0)
+
+
+@pytest.mark.parametrize("n", [64, 257, 1025])
+def test_potrf_f32(dev, n):
+    x, _ = _data(n, 2, seed=n)
+    ell, sf2, noise = 0.3, 1.0, 0.05
+    _, kbuf, ws, info = _factor(dev, x, ell, sf2, noise, torch.float32)
+    assert int(info.item()) == 0
+    lmat = np.tril(kbuf[:n, :n].double().cpu().numpy())
+    k = oracle.rbf_gram(x, None, ell, sf2, noise)
+    # backward error of the factorisation: |L L^T - K| / |K|  (f32 eps ~ 6e-8, n terms)
+    assert _relerr(lmat @ lmat.T, k) < 2e-5
+
+
+def test_potrf_reports_first_bad_pivot(dev):
+    x = np.array([[0.0], [0.5], [0.5], [1.0]] + [[2.0 + i] for i in range(70)])   # duplicated point, no noise
+    _, _, _, info = _factor(dev, x, 1.0, 1.0, 0.0, torch.float64)
+    _, ref = oracle.potrf_lower(oracle.rbf_gram(x, None, 1.0, 1.0, 0.0))
+    assert ref == 3
+    assert int(info.item()) == 3
+    with pytest.raises(np.linalg.LinAlgError):
+        dev.raise_if_not_pd(info)
+
+
+@pytest.mark.parametrize("dt,tol", [("f64", 1e-9), ("f32", 5e-3)])
+@pytest.mark.parametrize("n,q", [(1, 2), (64, 2), (65, 1), (257, 3), (700, 2), (1025, 8)])
+def test_potrs(dev, dt, tol, n, q):
+    x, y = _data(n, 1, seed=n, q=max(q, 2))
+    y = y[:, :q]
+    ell, sf2, noise = 0.3, 1.0, 0.02
+    tdt = getattr(torch, TDT[dt])
+    _, kbuf, ws, info = _factor(dev, x, ell, sf2, noise, tdt)
+    rhs = dev.to_device(y, tdt, "cuda")
+    z = dev.potrs(kbuf, n, ws, rhs, want_z=True)
+    assert int(info.item()) == 0
+    fit = oracle.block_fit(x, y, ell, sf2, noise)
+    assert _relerr(z.double().cpu().numpy(), fit["z"]) < tol
+    assert _relerr(rhs.double().cpu().numpy(), fit["alpha"]) < tol
+
+
+@pytest.mark.parametrize("n,m", [(64, 5), (257, 130), (700, 64), (512, 1000)])
+def test_trsm_rows_f64(dev, n, m):
+    x, _ = _data(n, 2, seed=n)
+    xs, _ = _data(m, 2, seed=n + 1)
+    ell, sf2, noise = 0.5, 1.2, 0.01
+    xd, kbuf, ws, _ = _factor(dev, x, ell, sf2, noise, torch.float64)
+    w = dev.rbf_cross(dev.to_device(xs, torch.float64, "cuda"), xd, ell, sf2)
+    dev.trsm_rows(kbuf, n, ws, w, m)
+    lref, _ = oracle.potrf_lower(oracle.rbf_gram(x, None, ell, sf2, noise))
+    ref = sla.solve_triangular(lref, oracle.rbf_gram(xs, x, ell, sf2).T, lower=True).T
+    assert _relerr(w[:m, :n].cpu().numpy(), ref) < 1e-9
+
+
+@pytest.mark.parametrize("dt,tol", [("f64", 1e-9), ("f32", 2e-3)])
+@pytest.mark.parametrize("n,ns,d", [(64, 1, 1), (257, 37, 2), (600, 1000, 1)])
+def test_predict_mean_and_variance(dev, dt, tol, n, ns, d):
+    x, y = _data(n, d, seed=n)
+    xs, _ = _data(ns, d, seed=n + 7)
+    ell, sf2, noise = 0.4, 1.3, 0.02
+    tdt = getattr(torch, TDT[dt])
+    xd, kbuf, ws, _ = _factor(dev, x, ell, sf2, noise, tdt)
+    alpha = dev.to_device(y, tdt, "cuda")
+    z = dev.potrs(kbuf, n, ws, alpha, want_z=True)
+    xsd = dev.to_device(xs, tdt, "cuda")
+    bias = dev.to_device(np.array([0.25, -1.5]), tdt, "cuda")
+    fit = oracle.block_fit(x, y, ell, sf2, noise)
+    mref, vref = oracle.block_predict(x, fit, xs, ell, sf2, True)
+    # D4 fused mean, overwrite then accumulate
+    m1 = dev.predict_mean(xd, alpha, xsd, ell, sf2, bias)
+    assert _relerr(m1.double().cpu().numpy(), mref + np.array([0.25, -1.5])) < tol
+    dev.predict_mean(xd, alpha, xsd, ell, sf2, None, out=m1, accumulate=True)
+    assert _relerr(m1.double().cpu().numpy(), 2 * mref + np.array([0.25, -1.5])) < tol
+    # D5 through W = K* L^-T
+    w = dev.rbf_cross(xsd, xd, ell, sf2)
+    dev.trsm_rows(kbuf, n, ws, w, ns)
+    mean = torch.zeros((ns, 2), dtype=tdt, device="cuda")
+    var = torch.zeros(ns, dtype=tdt, device="cuda")
+    dev.predict_from_w(w, ns, n, z, sf2, 0.0, None, mean, var, accumulate=False)
+    assert _relerr(mean.double().cpu().numpy(), mref) < tol
+    # variance is a difference of near-equal numbers: compare on the scale of sf2
+    assert float(np.max(np.abs(var.double().cpu().numpy() - vref))) / sf2 < tol
+
+
+def test_residual_chain_helpers(dev):
+    rng = np.random.default_rng(3)
+    n, q = 1000, 2
+    y = rng.normal(size=(n, q)) * np.array([1.0, 3.0]) + np.array([0.5, -2.0])
+    fbar = rng.normal(size=(n, q)) * 0.1
+    yd, fd = (dev.to_device(a, torch.float64, "cuda") for a in (y, fbar))
+    stats = dev.block_stats(yd, fd)
+    r = y - fbar
+    bias = r.mean(axis=0)
+    pooled = np.mean((r - bias) ** 2)
+    np.testing.assert_allclose(stats.cpu().numpy(), np.r_[bias, pooled], rtol=1e-12)
+    noise = dev.noise_from_stats(stats, q, 0.01, 1e-8)
+    np.testing.assert_allclose(noise.item(), 0.01 * pooled, rtol=1e-12)
+    assert dev.noise_from_stats(stats, q, 0.0, 1e-8).item() == 1e-8
+    rd = dev.residual(yd, fd, stats[:q])
+    np.testing.assert_allclose(rd.cpu().numpy(), r - bias, rtol=0, atol=1e-14)
+    alpha = rng.normal(size=(n, q))
+    out = torch.ones((n, q), dtype=torch.float64, device="cuda")
+    dev.train_mean(rd, dev.to_device(alpha, torch.float64, "cuda"), stats[:q], noise, out, accumulate=True)
+    np.testing.assert_allclose(out.cpu().numpy(), 1 + (r - bias) - 0.01 * pooled * alpha + bias, rtol=1e-12, atol=1e-13)
+    # stats with fbar = None
+    np.testing.assert_allclose(dev.block_stats(yd, None).cpu().numpy()[:q], y.mean(axis=0), rtol=1e-12)
+    # add_diag and log-determinant
+    x, _ = _data(300, 1, seed=4)
+    xd = dev.to_device(x, torch.float64, "cuda")
+    kbuf = dev.rbf_gram(xd, 0.3, 1.0, 0.0, lower_only=True)
+    dev.add_diag(kbuf, 300, noise)
+    kref = oracle.rbf_gram(x, None, 0.3, 1.0, float(noise.item()))
+    np.testing.assert_allclose(np.diag(kbuf[:300, :300].cpu().numpy()), np.diag(kref), rtol=1e-14)
+    dev.potrf(kbuf, 300)
+    lref, _ = oracle.potrf_lower(kref)
+    np.testing.assert_allclose(dev.logdet_half(kbuf, 300).item(), np.sum(np.log(np.diag(lref))), rtol=1e-10)
+
+
+def test_dense_golden_fixtures(dev, golden_dir):
+    g = np.load(os.path.join(golden_dir, "dense_oracle.npz"))
+    for tag in ["n64_d1", "n257_d2", "n512_d1"]:
+        x, y, xs = g[tag + "_x"], g[tag + "_y"], g[tag + "_xs"]
+        ell, sf2, noise = (float(v) for v in g[tag + "_hyp"])
+        n = x.shape[0]
+        xd, kbuf, ws, info = _factor(dev, x, ell, sf2, noise, torch.float64)
+        assert int(info.item()) == 0
+        lmat = kbuf[:n, :n].cpu().numpy()
+        np.testing.assert_allclose(np.diag(lmat), g[tag + "_Ldiag"], rtol=1e-9)
+        np.testing.assert_allclose(lmat[-1], g[tag + "_Llast"], rtol=0, atol=1e-9)
+        alpha = dev.to_device(y, torch.float64, "cuda")
+        z = dev.potrs(kbuf, n, ws, alpha, want_z=True)
+        assert _relerr(alpha.cpu().numpy(), g[tag + "_alpha"]) < 1e-8
+        assert _relerr(z.cpu().numpy(), g[tag + "_z"]) < 1e-9
+        xsd = dev.to_device(xs, torch.float64, "cuda")
+        m = dev.predict_mean(xd, alpha, xsd, ell, sf2, None)
+        assert _relerr(m.cpu().numpy(), g[tag + "_mean"]) < 1e-9
