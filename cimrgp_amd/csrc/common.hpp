@@ -22,6 +22,13 @@ int  check_hip(hipError_t e, const char* fn, const char* what);
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+#ifdef CIMRGP_STAMP   // diagnostic builds only (tools/diag_probe.hip): phase stamps of workgroup 0
+__device__ long long g_stamp[32];
+#define STAMP(n) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_stamp[n] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(n) do { } while (0)
+#endif
+
 // ------------------------------------------------------------ MFMA traits ----
 // 16x16x4 matrix-core tiles, one 8-byte "k-slot" per lane per operand:
 //   lane l supplies A[row = l & 15][kslot = l >> 4] and B^T[col = l & 15][kslot = l >> 4].
@@ -36,6 +43,7 @@ template <> struct Mx<double> {
     static constexpr int EPS = 1;     // elements per 8-byte k-slot
     // C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 r
     static __device__ __forceinline__ int crow(int lane, int r) { return (lane >> 4) + 4 * r; }
+    static __device__ __forceinline__ uint2 neg(uint2 a) { a.y ^= 0x80000000u; return a; }
     static __device__ __forceinline__ acc_t mma(uint2 a, uint2 b, acc_t c) {
         double da = __hiloint2double((int)a.y, (int)a.x);
         double db = __hiloint2double((int)b.y, (int)b.x);
@@ -49,6 +57,7 @@ template <> struct Mx<float> {
     static constexpr int EPS = 2;
     // C/D map of v_mfma_f32_16x16x4_f32: col = lane & 15, row = 4 (lane >> 4) + r
     static __device__ __forceinline__ int crow(int lane, int r) { return 4 * (lane >> 4) + r; }
+    static __device__ __forceinline__ uint2 neg(uint2 a) { a.x ^= 0x80000000u; a.y ^= 0x80000000u; return a; }
     static __device__ __forceinline__ acc_t mma(uint2 a, uint2 b, acc_t c) {
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
@@ -77,6 +86,15 @@ __device__ __forceinline__ uint4 mask_chunk<float>(uint4 v, int kfirst, int kval
     if (kfirst + 1 >= kvalid) v.y = 0;
     if (kfirst + 2 >= kvalid) v.z = 0;
     if (kfirst + 3 >= kvalid) v.w = 0;
+    return v;
+}
+
+// Flip the sign of every element of a 16-byte chunk.
+template <typename T> static __device__ __forceinline__ uint4 neg_chunk(uint4 v);
+template <> __device__ __forceinline__ uint4 neg_chunk<double>(uint4 v) { v.y ^= 0x80000000u; v.w ^= 0x80000000u; return v; }
+template <> __device__ __forceinline__ uint4 neg_chunk<float>(uint4 v)
+{
+    v.x ^= 0x80000000u; v.y ^= 0x80000000u; v.z ^= 0x80000000u; v.w ^= 0x80000000u;
     return v;
 }
 

@@ -26,7 +26,10 @@ constexpr int LROW     = KT_BYTES + 16;  // LDS row stride
 constexpr int OP_BYTES = GT * LROW;      // one operand, one stage
 constexpr int SMEM     = 4 * OP_BYTES;   // {A,B} x 2 stages = 73,728 B
 
-template <typename T, bool LOWER>
+// EDGE = false: M, N multiples of 128 and K a multiple of the stage depth -- no bounds logic
+// at all (every select on a prefetched register makes hipcc wait for it right behind the
+// load).  EDGE = true: ragged sizes, zero-fill and predicated stores.
+template <typename T, bool LOWER, bool EDGE>
 __global__ __launch_bounds__(256, 2)
 void k_gemm_nt_sub(T* __restrict__ C, int64_t ldc,
                    const T* __restrict__ A, int64_t lda,
@@ -61,57 +64,97 @@ void k_gemm_nt_sub(T* __restrict__ C, int64_t ldc,
     const int sr = tid >> 3;
     const int nkt = (K + BKE - 1) / BKE;
 
-    const T* a_ptr[4];
-    const T* b_ptr[4];
+    // Staging addresses: uniform tile base (SGPRs) + one 32-bit per-thread element offset per
+    // operand row group, so the 8 loads of a stage need 8 VGPRs of addressing, not 16.
     bool a_ok[4], b_ok[4];
+    int a_off_e[4], b_off_e[4];
+    const T* a_tile = A + (int64_t)row0 * lda;
+    const T* b_tile = B + (int64_t)col0 * ldb;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int r = sr + 32 * p;
         a_ok[p] = (row0 + r) < M;
         b_ok[p] = (col0 + r) < N;
-        a_ptr[p] = A + (int64_t)(a_ok[p] ? row0 + r : 0) * lda + sc * X::EPC;
-        b_ptr[p] = B + (int64_t)(b_ok[p] ? col0 + r : 0) * ldb + sc * X::EPC;
+        a_off_e[p] = ((EDGE && !a_ok[p]) ? 0 : r) * (int)lda + sc * X::EPC;
+        b_off_e[p] = ((EDGE && !b_ok[p]) ? 0 : r) * (int)ldb + sc * X::EPC;
     }
 
     uint4 ra[4], rb[4];
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
 
+    // GLOAD only ISSUES the loads (clamped, always valid addresses); every use of the loaded
+    // registers (zero-fill of out-of-range rows/columns) is in SWRITE, after the MFMA block,
+    // so the s_waitcnt lands there and the loads fly during the multiply.  The sign flip that
+    // turns the chain into C - A B^T is applied to the A fragments after the LDS read (one
+    // XOR per fragment and 16 MFMAs); flipping the staged registers component-wise makes
+    // hipcc shuffle them right behind the loads and wait there.
 #define CIMRGP_GLOAD(kt_)                                                        \
     {                                                                            \
+        const int kcol = (kt_) * BKE + sc * X::EPC;                              \
+        const int koff = (!EDGE || kcol < K) ? (kt_) * BKE : 0;                  \
+        _Pragma("unroll") for (int p = 0; p < 4; ++p) {                          \
+            ra[p] = *reinterpret_cast<const uint4*>(a_tile + (a_off_e[p] + koff)); \
+            rb[p] = *reinterpret_cast<const uint4*>(b_tile + (b_off_e[p] + koff)); \
+        }                                                                        \
+    }
+#define CIMRGP_SWRITE(buf_, kt_)                                                 \
+    {                                                                            \
+        unsigned char* as_ = smem + (buf_) * 2 * OP_BYTES;                       \
+        unsigned char* bs_ = as_ + OP_BYTES;                                     \
         const int kcol = (kt_) * BKE + sc * X::EPC;                              \
         const bool kin = kcol < K;                                               \
         const bool kfull = kcol + X::EPC <= K;                                   \
         _Pragma("unroll") for (int p = 0; p < 4; ++p) {                          \
-            uint4 va = zero4, vb = zero4;                                        \
-            if (a_ok[p] && kin) va = *reinterpret_cast<const uint4*>(a_ptr[p] + (kt_) * BKE); \
-            if (b_ok[p] && kin) vb = *reinterpret_cast<const uint4*>(b_ptr[p] + (kt_) * BKE); \
-            if (!kfull) { va = mask_chunk<T>(va, kcol, K); vb = mask_chunk<T>(vb, kcol, K); } \
-            ra[p] = va; rb[p] = vb;                                              \
+            uint4 va = ra[p], vb = rb[p];                                        \
+            if (EDGE) {                                                          \
+                if (!(a_ok[p] && kin)) va = zero4;                               \
+                if (!(b_ok[p] && kin)) vb = zero4;                               \
+                if (!kfull) { va = mask_chunk<T>(va, kcol, K); vb = mask_chunk<T>(vb, kcol, K); } \
+            }                                                                    \
+            *reinterpret_cast<uint4*>(as_ + (sr + 32 * p) * LROW + sc * 16) = va; \
+            *reinterpret_cast<uint4*>(bs_ + (sr + 32 * p) * LROW + sc * 16) = vb; \
         }                                                                        \
     }
-#define CIMRGP_SWRITE(buf_)                                                      \
-    {                                                                            \
-        unsigned char* as_ = smem + (buf_) * 2 * OP_BYTES;                       \
-        unsigned char* bs_ = as_ + OP_BYTES;                                     \
-        _Pragma("unroll") for (int p = 0; p < 4; ++p) {                          \
-            *reinterpret_cast<uint4*>(as_ + (sr + 32 * p) * LROW + sc * 16) = ra[p]; \
-            *reinterpret_cast<uint4*>(bs_ + (sr + 32 * p) * LROW + sc * 16) = rb[p]; \
-        }                                                                        \
-    }
-
-    acc_t acc[4][4];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = acc_zero<T>();
 
     const int frow = lane & 15, fslot = lane >> 4;
     const unsigned a_off = (unsigned)((wr * 64 + frow) * LROW + fslot * 8);
     const unsigned b_off = (unsigned)((wc * 64 + frow) * LROW + fslot * 8);
 
+    STAMP(16);
     CIMRGP_GLOAD(0);
-    CIMRGP_SWRITE(0);
+    // The accumulators start as the C tile and the A fragments are NEGATED, so the MFMA
+    // chain itself computes C - A B^T: the 64 C loads per lane are independent and in flight
+    // together with the first operand tiles, and the epilogue is stores only.  (A read-modify-
+    // write epilogue serialises 64 dependent load->store round trips per lane.)
+    const bool diag_tile = LOWER && (ti == tj);
+    acc_t acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int gc = col0 + wc * 64 + ni * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gr = row0 + wr * 64 + mi * 16 + X::crow(lane, r);
+                // unconditional load from a clamped (always valid) address, then select
+                if (EDGE) {
+                    const T v = C[(int64_t)min(gr, M - 1) * ldc + min(gc, N - 1)];
+                    acc[mi][ni][r] = (gr < M && gc < N && (!diag_tile || gc <= gr)) ? v : (T)0;
+                } else {
+                    acc[mi][ni][r] = C[(int64_t)gr * ldc + gc];     // junk above the diagonal is never stored
+                }
+            }
+        }
+    }
+    CIMRGP_SWRITE(0, 0);
+    // Make the C loads complete HERE: otherwise hipcc guards the first MFMA of every loop
+    // iteration with s_waitcnt vmcnt(0), which also drains the operand prefetch just issued.
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) asm volatile("" : "+v"(acc[mi][ni]));
     __syncthreads();
+    STAMP(17);
 
     for (int kt = 0; kt < nkt; ++kt) {
         const bool more = (kt + 1) < nkt;
@@ -123,7 +166,7 @@ void k_gemm_nt_sub(T* __restrict__ C, int64_t ldc,
             uint2 a[4], b[4];
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
-                a[mi] = *reinterpret_cast<const uint2*>(as + a_off + mi * 16 * LROW + s * 32);
+                a[mi] = X::neg(*reinterpret_cast<const uint2*>(as + a_off + mi * 16 * LROW + s * 32));
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
                 b[ni] = *reinterpret_cast<const uint2*>(bs + b_off + ni * 16 * LROW + s * 32);
@@ -132,14 +175,16 @@ void k_gemm_nt_sub(T* __restrict__ C, int64_t ldc,
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = X::mma(a[mi], b[ni], acc[mi][ni]);
         }
-        if (more) CIMRGP_SWRITE((kt + 1) & 1);
+        if (more) CIMRGP_SWRITE((kt + 1) & 1, kt + 1);
         __syncthreads();
     }
 #undef CIMRGP_GLOAD
 #undef CIMRGP_SWRITE
 
-    // epilogue: C -= acc   (f64 map: 16 lanes x 8 B = one 128-byte line per row)
-    const bool diag_tile = LOWER && (ti == tj);
+    STAMP(18);
+    int Mv = M, Nv = N;
+    asm volatile("" : "+s"(Mv), "+s"(Nv));      // recompute the store predicates here (not hoisted over the loop)
+    // epilogue: store the tile (f64 map: 16 lanes x 8 B = one 128-byte line per row)
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
@@ -148,13 +193,11 @@ void k_gemm_nt_sub(T* __restrict__ C, int64_t ldc,
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gr = row0 + wr * 64 + mi * 16 + X::crow(lane, r);
-                if (gr < M && gc < N && (!diag_tile || gc <= gr)) {
-                    T* p = C + (int64_t)gr * ldc + gc;
-                    *p = *p - acc[mi][ni][r];
-                }
+                if ((!EDGE || (gr < Mv && gc < Nv)) && (!diag_tile || gc <= gr)) C[(int64_t)gr * ldc + gc] = acc[mi][ni][r];
             }
         }
     }
+    STAMP(19);
 }
 
 }  // namespace
@@ -169,17 +212,22 @@ int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t 
     CIMRGP_REQUIRE(aligned16(a) && aligned16(b), fn, "operand base not 16-byte aligned");
     CIMRGP_REQUIRE(lda % Mx<T>::EPC == 0 && ldb % Mx<T>::EPC == 0, fn, "leading dimension not a multiple of 16 bytes");
     const int64_t tm = (m + GT - 1) / GT, tn = (n + GT - 1) / GT;
+    const bool edge = (m % GT) != 0 || (n % GT) != 0 || (k % (KT_BYTES / (int)sizeof(T))) != 0;
     if (lower) {
         CIMRGP_REQUIRE(m == n, fn, "lower update needs a square C");
         const int64_t tiles = tm * (tm + 1) / 2;
         CIMRGP_REQUIRE(tiles < (1ll << 31), fn, "grid too large");
-        hipLaunchKernelGGL((k_gemm_nt_sub<T, true>), dim3((unsigned)tiles), dim3(256), 0, st,
-                           c, ldc, a, lda, b, ldb, (int)m, (int)n, k, (int)tn);
+        if (edge) hipLaunchKernelGGL((k_gemm_nt_sub<T, true, true>), dim3((unsigned)tiles), dim3(256), 0, st,
+                                     c, ldc, a, lda, b, ldb, (int)m, (int)n, k, (int)tn);
+        else      hipLaunchKernelGGL((k_gemm_nt_sub<T, true, false>), dim3((unsigned)tiles), dim3(256), 0, st,
+                                     c, ldc, a, lda, b, ldb, (int)m, (int)n, k, (int)tn);
     } else {
         const int64_t tiles = tm * tn;
         CIMRGP_REQUIRE(tiles < (1ll << 31), fn, "grid too large");
-        hipLaunchKernelGGL((k_gemm_nt_sub<T, false>), dim3((unsigned)tiles), dim3(256), 0, st,
-                           c, ldc, a, lda, b, ldb, (int)m, (int)n, k, (int)tn);
+        if (edge) hipLaunchKernelGGL((k_gemm_nt_sub<T, false, true>), dim3((unsigned)tiles), dim3(256), 0, st,
+                                     c, ldc, a, lda, b, ldb, (int)m, (int)n, k, (int)tn);
+        else      hipLaunchKernelGGL((k_gemm_nt_sub<T, false, false>), dim3((unsigned)tiles), dim3(256), 0, st,
+                                     c, ldc, a, lda, b, ldb, (int)m, (int)n, k, (int)tn);
     }
     CIMRGP_LAUNCH_CHECK(fn);
     return 0;

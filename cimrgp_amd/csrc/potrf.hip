@@ -2,11 +2,10 @@
 // triangular solve that shares its panel kernels.
 //
 //   for each panel of CIMRGP_NB = 256 columns:
-//     for each 64-column sub-block s of the panel:
-//        k_diag64   one workgroup: factor the 64x64 diagonal block in LDS and
-//                   form its inverse alongside (one barrier per column)
-//        k_trsm64   rows below: X = P * inv(L_ss)^T      (MFMA, K = 64, in place)
-//        gemm_nt    remaining panel columns -= X * X_panel^T   (MFMA, K = 64)
+//     for each 64-column sub-block s of the panel (left-looking inside the panel):
+//        k_diag64   one workgroup: A_ss -= L_s,prev L_s,prev^T (MFMA), factor the
+//                   64x64 block from registers and form its inverse alongside
+//        k_trsm64   rows below: X = (P_s - P_prev L_s,prev^T) inv(L_ss)^T  (MFMA, in place)
 //     gemm_nt (lower)  trailing matrix -= panel * panel^T       (MFMA, K = 256)
 //
 // The inverted 64x64 diagonal blocks stay in the workspace (slab c0/64) and
@@ -63,7 +62,7 @@ static TrailRec* rec_open(hipStream_t st, double flops)
         if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return nullptr;
     }
     r.flops = flops;
-    hipEventRecord(r.start, st);
+    (void)hipEventRecord(r.start, st);
     g_recs.push_back(r);
     return &g_recs.back();
 }
@@ -72,121 +71,364 @@ namespace {
 
 constexpr int SB = 64;   // diagonal sub-block
 
-// ---------------------------------------------------------------------------
-// 64x64 diagonal block:  D = L L^T in place (lower), inv slab = L^-1 (lower,
-// zero above the diagonal and outside w x w).
-// Working copies S (unscaled Schur complement) and Mi (unscaled inverse rows)
-// live in LDS; column j of L is S[:,j] * r_j and row j of L^-1 is Mi[j,:] * r_j
-// with r_j = 1/sqrt(S[j][j]).  During step j nobody writes column j of S or
-// row j of Mi, so one barrier per column is enough.
-// ---------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256)
-void k_diag64(T* __restrict__ D, int64_t ld, int w, T* __restrict__ inv, int32_t* info, int col_base)
+
+template <typename T> struct Tile64 {
+    static constexpr int ROWB  = SB * (int)sizeof(T);   // bytes of 64 k-values per row
+    static constexpr int LROW  = ROWB + 16;              // padded LDS row stride
+    static constexpr int CPR   = ROWB / 16;              // 16-byte chunks per row
+    static constexpr int NSTEP = ROWB / 32;              // slot-steps (4 slots x 8 B) per 64 k
+    static constexpr int KPS   = 32 / (int)sizeof(T);    // k values per slot-step
+    static constexpr int BYTES = SB * LROW;
+};
+
+// Cooperative, coalesced load of a 64 x kw strip (row stride ld elements) into a
+// padded LDS tile; rows >= mrows and columns >= kw are zero-filled.
+template <typename T, int ROWS = SB>
+static __device__ __forceinline__ void load_tile64(unsigned char* dst, const T* __restrict__ src, int64_t ld,
+                                                    int mrows, int kw)
 {
-    constexpr int LS = SB + 1;
-    __shared__ T S[SB * LS];
-    __shared__ T Mi[SB * LS];
-    const int tid = threadIdx.x;
-    const int i  = tid & 63;      // row owned in the update phase
-    const int kg = tid >> 6;      // column group 0..3 (wave-uniform)
-
-    for (int e = tid; e < SB * SB; e += 256) {
-        const int r = e >> 6, c = e & 63;
-        T v = (r == c) ? (T)1 : (T)0;
-        if (r < w && c <= r) v = D[(int64_t)r * ld + c];
-        S[r * LS + c]  = v;
-        Mi[r * LS + c] = (r == c) ? (T)1 : (T)0;
-        inv[e] = (T)0;
-    }
-
-    for (int j = 0; j < w; ++j) {
-        __syncthreads();
-        const T d = S[j * LS + j];
-        if (!(d > (T)0)) {
-            if (tid == 0) atomicCAS(info, 0, col_base + j + 1);
+    using X = Mx<T>;
+    using TL = Tile64<T>;
+    for (int e = threadIdx.x; e < ROWS * TL::CPR; e += 256) {
+        const int r = e / TL::CPR, c = e - r * TL::CPR;
+        const int kcol = c * X::EPC;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < mrows && kcol < kw) {
+            v = *reinterpret_cast<const uint4*>(src + (int64_t)r * ld + kcol);
+            if (kcol + X::EPC > kw) v = mask_chunk<T>(v, kcol, kw);
         }
-        const T r  = (T)1 / sqrt(d);
-        const T li = S[i * LS + j] * r;          // L[i][j] for i >= j
-        if (kg == 0) {
-            if (i >= j && i < w) D[(int64_t)i * ld + j] = (i == j) ? d * r : li;
-        } else if (kg == 1) {
-            if (i <= j) inv[j * SB + i] = Mi[j * LS + i] * r;
-        }
-        if (i > j) {
-            for (int k = j + 1 + kg; k <= i; k += 4)
-                S[i * LS + k] -= li * (S[k * LS + j] * r);
-            for (int c = kg; c <= j; c += 4)
-                Mi[i * LS + c] -= li * (Mi[j * LS + c] * r);
-        }
+        *reinterpret_cast<uint4*>(dst + r * TL::LROW + c * 16) = v;
     }
 }
 
-// ---------------------------------------------------------------------------
-// X = P * invL^T for a 64-column strip P (M rows, kw <= 64 valid columns),
-// in place.  invL is a 64x64 lower slab.  One workgroup = 64 rows; each wave
-// owns 16 rows x 64 columns (4 MFMA tiles); the whole K = 64 is resident in
-// LDS, so every row is read completely before it is overwritten.
-// Column tile ct only needs k <= 16 ct + 15 (invL is lower triangular).
-// ---------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256)
-void k_trsm64(T* __restrict__ P, int64_t ldp, int M, int kw, const T* __restrict__ invL)
+// Same strip, split in two halves so the global loads of the next k chunk can be in
+// flight (in registers) while the current chunk is multiplied.
+template <typename T, int ROWS>
+static __device__ __forceinline__ void gload_tile64(uint4 (&regs)[ROWS * Tile64<T>::CPR / 256], const T* __restrict__ src,
+                                                     int64_t ld, int mrows, int kw)
 {
     using X = Mx<T>;
-    using acc_t = typename X::acc_t;
-    constexpr int ROWB = SB * (int)sizeof(T);       // bytes of K per row
-    constexpr int LROW = ROWB + 16;                 // padded LDS row stride
-    constexpr int CPR  = ROWB / 16;                 // 16-byte chunks per row
-    constexpr int NSTEP = ROWB / 32;                // slot-steps (4 slots of 8 B each)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * SB * LROW];
-    unsigned char* ps = smem;
-    unsigned char* ls = smem + SB * LROW;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.x * SB;
-
-    for (int e = tid; e < SB * CPR; e += 256) {
-        const int r = e / CPR, c = e - r * CPR;
+    using TL = Tile64<T>;
+#pragma unroll
+    for (int p = 0; p < ROWS * TL::CPR / 256; ++p) {
+        const int e = threadIdx.x + 256 * p;
+        const int r = e / TL::CPR, c = e - r * TL::CPR;
         const int kcol = c * X::EPC;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (row0 + r < M && kcol < kw) {
-            v = *reinterpret_cast<const uint4*>(P + (int64_t)(row0 + r) * ldp + kcol);
+        if (r < mrows && kcol < kw) {
+            v = *reinterpret_cast<const uint4*>(src + (int64_t)r * ld + kcol);
             if (kcol + X::EPC > kw) v = mask_chunk<T>(v, kcol, kw);
         }
-        *reinterpret_cast<uint4*>(ps + r * LROW + c * 16) = v;
-        *reinterpret_cast<uint4*>(ls + r * LROW + c * 16) =
-            *reinterpret_cast<const uint4*>(invL + r * SB + kcol);
+        regs[p] = v;
     }
-    __syncthreads();
+}
 
-    acc_t acc[4];
+template <typename T, int ROWS>
+static __device__ __forceinline__ void swrite_tile64(unsigned char* dst, const uint4 (&regs)[ROWS * Tile64<T>::CPR / 256])
+{
+    using TL = Tile64<T>;
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) acc[ct] = acc_zero<T>();
+    for (int p = 0; p < ROWS * TL::CPR / 256; ++p) {
+        const int e = threadIdx.x + 256 * p;
+        const int r = e / TL::CPR, c = e - r * TL::CPR;
+        *reinterpret_cast<uint4*>(dst + r * TL::LROW + c * 16) = regs[p];
+    }
+}
+
+// acc[ct] += A(16 rows of this wave) * B(rows 16 ct ..)^T over one 64-wide k chunk.
+template <typename T, bool TRI>
+static __device__ __forceinline__ void mma_chunk64(typename Mx<T>::acc_t (&acc)[4], const unsigned char* as,
+                                                    const unsigned char* bs, int wave, int lane)
+{
+    using X = Mx<T>;
+    using TL = Tile64<T>;
     const int frow = lane & 15, fslot = lane >> 4;
-    const unsigned char* pa = ps + (wave * 16 + frow) * LROW + fslot * 8;
-    const unsigned char* pb = ls + frow * LROW + fslot * 8;
-    constexpr int KPS = 32 / (int)sizeof(T);        // k values per slot-step
+    const unsigned char* pa = as + (wave * 16 + frow) * TL::LROW + fslot * 8;
+    const unsigned char* pb = bs + frow * TL::LROW + fslot * 8;
 #pragma unroll
-    for (int s = 0; s < NSTEP; ++s) {
+    for (int s = 0; s < TL::NSTEP; ++s) {
         const uint2 a = *reinterpret_cast<const uint2*>(pa + s * 32);
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
-            if (s * KPS <= 16 * ct + 15) {   // compile-time after unrolling
-                const uint2 b = *reinterpret_cast<const uint2*>(pb + ct * 16 * LROW + s * 32);
+            // TRI: B is lower triangular (B[j][k] = 0 for k > j): column tile ct needs k <= 16 ct + 15
+            if (!TRI || (s * TL::KPS <= 16 * ct + 15)) {
+                const uint2 b = *reinterpret_cast<const uint2*>(pb + ct * 16 * TL::LROW + s * 32);
                 acc[ct] = X::mma(a, b, acc[ct]);
             }
         }
     }
+}
+
+// 32-row variant: wave = (rt = row tile 0/1, ch = column half 0/1): 16 rows x 32 columns.
+template <typename T, bool TRI>
+static __device__ __forceinline__ void mma_chunk32(typename Mx<T>::acc_t (&acc)[2], const unsigned char* as,
+                                                    const unsigned char* bs, int rt, int ch, int lane)
+{
+    using X = Mx<T>;
+    using TL = Tile64<T>;
+    const int frow = lane & 15, fslot = lane >> 4;
+    const unsigned char* pa = as + (rt * 16 + frow) * TL::LROW + fslot * 8;
+    const unsigned char* pb = bs + (ch * 32 + frow) * TL::LROW + fslot * 8;
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-        const int gc = ct * 16 + (lane & 15);
+    for (int s = 0; s < TL::NSTEP; ++s) {
+        // TRI: column tile ct = 2 ch + c needs k <= 16 ct + 15; ch is run-time (wave-uniform)
+        if (!TRI || (s * TL::KPS <= 16 * (2 * ch + 1) + 15)) {
+            const uint2 a = *reinterpret_cast<const uint2*>(pa + s * 32);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int gr = row0 + wave * 16 + X::crow(lane, r);
-            if (gr < M && gc < kw) P[(int64_t)gr * ldp + gc] = acc[ct][r];
+            for (int c = 0; c < 2; ++c) {
+                if (!TRI || (s * TL::KPS <= 16 * (2 * ch + c) + 15)) {
+                    const uint2 b = *reinterpret_cast<const uint2*>(pb + c * 16 * TL::LROW + s * 32);
+                    acc[c] = X::mma(a, b, acc[c]);
+                }
+            }
         }
     }
+}
+
+template <typename T> static __device__ __forceinline__ T rsqrt_refined(T d);
+template <> __device__ __forceinline__ double rsqrt_refined<double>(double d)
+{
+    double r = __builtin_amdgcn_rsq(d);          // ~2^-26; two Newton steps -> full f64
+    {
+        const double e0 = fma(-d * r, r, 1.0);
+        r = fma(0.5 * r, e0, r);
+    }
+    const double e = fma(-d * r, r, 1.0);       // one Newton step: full f64 accuracy
+    return fma(0.5 * r, e, r);
+}
+template <> __device__ __forceinline__ float rsqrt_refined<float>(float d)
+{
+    float r = rsqrtf(d);
+    const float e = fmaf(-d * r, r, 1.0f);
+    return fmaf(0.5f * r, e, r);
+}
+
+// ---------------------------------------------------------------------------
+// Diagonal 64x64 sub-block of a panel (left-looking inside the panel):
+//   S = A_ss - Lrow Lrow^T        Lrow = the kprev panel columns left of the
+//                                 block, already final (MFMA, K = kprev <= 192)
+//   S = L L^T  in place, inv slab = L^-1 (lower; zero elsewhere).
+// Factor and inverse advance together, one barrier per column.  Thread
+// (i = tid & 63, g = tid >> 6) keeps row i, columns k = g + 4u (u < 16) of the
+// unscaled Schur complement S and of the unscaled inverse Mi in REGISTERS; per
+// column only column j of S and row j of Mi travel through LDS (double
+// buffered).  Column j of L is S[:,j] r_j and row j of L^-1 is Mi[j,:] r_j,
+// r_j = 1/sqrt(S[j][j]); the row operations that reduce S are applied to Mi.
+// ---------------------------------------------------------------------------
+// LDS-only barrier: waits for this wave's LDS traffic, not for global stores in
+// flight (a plain __syncthreads() also drains vmcnt, i.e. every store's round trip).
+static __device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Register layout of the column loop: thread (i = tid & 63, g = tid >> 6) keeps row i,
+// columns k = 16 g + u (u < 16) of ONE combined 64x64 array A:
+//     A[i][k] = S[i][k]   for k <= i   (Schur complement, lower triangle)
+//     A[i][k] = Mi[k][i]  for k >  i   (unscaled inverse, stored transposed in the upper triangle)
+// At pivot j everything a thread needs is column j of A: A[i][j] is S[i][j] for i >= j and
+// Mi[j][i] for i < j, so the wave that owns column j publishes it with ONE LDS store, and
+//     A[i][k] -= (A[k][j] r) * h_i   for every k > j,    r = 1/sqrt(A[j][j]),
+//     h_i = L[i][j] = A[i][j] r (i > j),  L^-1[j][i] = A[i][j] r (i < j),  r (i = j, from 0)
+// covers the Schur update, the inverse update and the birth of column j of Mi in one
+// formula (for j < i < k it touches a not-yet-born Mi slot, which is reset at pivot i).
+// Waves left of the pivot column have nothing to do; register indices are compile-time
+// constants (u0 unrolled, wave index looped).
+template <typename T>
+__global__ __launch_bounds__(256)
+void k_diag64(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow, int kprev,
+              T* __restrict__ inv, int32_t* info, int col_base)
+{
+    using X = Mx<T>;
+    using TL = Tile64<T>;
+    using acc_t = typename X::acc_t;
+    constexpr int LS = SB + 1;
+    __shared__ __attribute__((aligned(16))) unsigned char chunk[TL::BYTES];   // Lrow chunk, later L^-1 out
+    __shared__ T S[SB * LS];                                                  // Schur block, later L out
+    __shared__ __attribute__((aligned(16))) T comb[2][SB];                    // column j of A
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int i = tid & 63;
+    const int g = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave id: provably uniform
+
+    STAMP(0);
+    for (int e = tid; e < SB * SB; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        T v = (r == c) ? (T)1 : (T)0;
+        if (r < w && c <= r) v = D[(int64_t)r * ld + c];
+        S[r * LS + c] = v;
+    }
+    STAMP(1);
+    if (kprev > 0) {
+        acc_t acc[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = acc_zero<T>();
+        for (int kc = 0; kc < kprev; kc += SB) {
+            __syncthreads();
+            load_tile64<T>(chunk, Lrow + kc, ld, w, min(SB, kprev - kc));
+            __syncthreads();
+            mma_chunk64<T, false>(acc, chunk, chunk, g, lane);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = g * 16 + X::crow(lane, r), col = ct * 16 + (lane & 15);
+                if (row < w && col <= row) S[row * LS + col] -= acc[ct][r];
+            }
+    }
+    __syncthreads();
+
+    T a[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) a[u] = S[i * LS + 16 * g + u];   // strict upper part of S is zero
+    T* lout = S;                                   // L[i][j]    at lout[i * LS + j]
+    T* iout = reinterpret_cast<T*>(chunk);         // L^-1[j][c] at iout[j * SB + c]
+    __syncthreads();
+    for (int e = tid; e < SB * SB; e += 256) iout[e] = (T)0;
+    STAMP(2);
+
+    for (int gg = 0; gg < 4; ++gg) {
+#pragma unroll
+        for (int u0 = 0; u0 < 16; ++u0) {
+            const int j = 16 * gg + u0;
+            if (j < w) {                             // uniform
+                T* cb = comb[j & 1];
+                if (g == gg) cb[i] = a[u0];          // the whole column j of A in one store
+                lds_barrier();
+                if (g >= gg) {
+                    const T d  = cb[j];
+                    const T ci = cb[i];
+                    const T r  = rsqrt_refined<T>(d);
+                    const T h  = (i == j) ? r : ci * r;
+                    if (g == gg) {
+                        if (!(d > (T)0) && i == j) atomicCAS(info, 0, col_base + j + 1);
+                        if (i >= j) lout[i * LS + j] = (i == j) ? d * r : h;
+                        else        iout[j * SB + i] = h;
+                        if (i == j) iout[j * SB + j] = r;
+                    }
+                    const T nhr = -h * r;            // A[i][k] -= A[k][j] * (h r)
+                    const bool pivot_row = (i == j);
+                    if (g > gg) {
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) {
+                            const T base = pivot_row ? (T)0 : a[u];
+                            a[u] = fma(nhr, cb[16 * g + u], base);
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) {
+                            if (u > u0) {
+                                const T base = pivot_row ? (T)0 : a[u];
+                                a[u] = fma(nhr, cb[16 * g + u], base);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    STAMP(3);
+    __syncthreads();
+    for (int e = tid; e < SB * SB; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        if (r < w && c <= r) D[(int64_t)r * ld + c] = lout[r * LS + c];
+        inv[e] = (r < w && c < w) ? iout[e] : (T)0;
+    }
+    STAMP(4);
+}
+
+// ---------------------------------------------------------------------------
+// Panel solve for one 64-column sub-block, left-looking inside the panel, in place:
+//   T = P_s - Pprev Lrow^T        Pprev = this row's kprev earlier panel columns (final),
+//                                 Lrow  = the diagonal block's rows, same columns
+//   X = T invL^T                  invL = 64x64 inverse of the diagonal block (lower)
+// One workgroup = 32 rows (each wave 16 rows x 32 columns = 2 MFMA tiles); a
+// row is read completely before it is overwritten and no other workgroup
+// touches it.  Two row sets share one launch (matrix rows below the block and
+// the extra right-hand-side rows of a row-wise solve).
+// ---------------------------------------------------------------------------
+constexpr int TR = 32;   // rows per workgroup of the panel solve
+
+template <typename T>
+__global__ __launch_bounds__(256)
+void k_trsm64(T* __restrict__ P1, int64_t ld1, int M1, int nb1,
+              T* __restrict__ P2, int64_t ld2, int M2,
+              int kw, int kprev, const T* __restrict__ Lrow, int64_t ldl, const T* __restrict__ invL)
+{
+    using X = Mx<T>;
+    using TL = Tile64<T>;
+    using acc_t = typename X::acc_t;
+    // 32 + 32 + 64 rows: 67.6 KB (f64) -- fits next to one resident trailing-update workgroup
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(2 * TR + SB) * TL::LROW];
+    unsigned char* ps = smem;                          // P_s, then T          (32 rows)
+    unsigned char* as = smem + TR * TL::LROW;          // chunk of Pprev       (32 rows)
+    unsigned char* bs = smem + 2 * TR * TL::LROW;      // chunk of Lrow, finally invL (64 rows)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rt = wave & 1, ch = wave >> 1;
+    const bool second = (int)blockIdx.x >= nb1;
+    T* P = second ? P2 : P1;
+    const int64_t ldp = second ? ld2 : ld1;
+    const int M = second ? M2 : M1;
+    const int row0 = (second ? (int)blockIdx.x - nb1 : (int)blockIdx.x) * TR;
+    const int mrows = min(TR, M - row0);
+    T* Prow = P + (int64_t)row0 * ldp;           // columns of this sub-block
+    const T* Pprev = Prow - kprev;               // the panel's earlier columns of the same rows
+
+    STAMP(8);
+    uint4 ra[TR * TL::CPR / 256], rb[SB * TL::CPR / 256];
+    if (kprev > 0) {
+        gload_tile64<T, TR>(ra, Pprev, ldp, mrows, SB);
+        gload_tile64<T, SB>(rb, Lrow, ldl, kw, SB);
+    }
+    load_tile64<T, TR>(ps, Prow, ldp, mrows, kw);
+    acc_t acc[2];
+    acc[0] = acc_zero<T>(); acc[1] = acc_zero<T>();
+    for (int kc = 0; kc < kprev; kc += SB) {
+        __syncthreads();                          // previous chunk's fragments have been read
+        swrite_tile64<T, TR>(as, ra);
+        swrite_tile64<T, SB>(bs, rb);
+        __syncthreads();
+        if (kc + SB < kprev) {                    // next chunk in flight during the MFMAs
+            gload_tile64<T, TR>(ra, Pprev + kc + SB, ldp, mrows, SB);
+            gload_tile64<T, SB>(rb, Lrow + kc + SB, ldl, kw, SB);
+        }
+        mma_chunk32<T, false>(acc, as, bs, rt, ch, lane);
+    }
+    __syncthreads();
+    STAMP(9);
+    // T = P_s - acc (each lane owns its accumulator elements), and stage invL
+    if (kprev > 0) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rt * 16 + X::crow(lane, r), col = (2 * ch + c) * 16 + (lane & 15);
+                T* t = reinterpret_cast<T*>(ps + row * TL::LROW) + col;
+                *t -= acc[c][r];
+            }
+    }
+    for (int e = tid; e < SB * TL::CPR; e += 256) {
+        const int r = e / TL::CPR, c = e - r * TL::CPR;
+        *reinterpret_cast<uint4*>(bs + r * TL::LROW + c * 16) =
+            *reinterpret_cast<const uint4*>(invL + r * SB + c * X::EPC);
+    }
+    __syncthreads();
+    acc[0] = acc_zero<T>(); acc[1] = acc_zero<T>();
+    STAMP(10);
+    mma_chunk32<T, true>(acc, ps, bs, rt, ch, lane);
+    STAMP(11);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int gc = (2 * ch + c) * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int lr = rt * 16 + X::crow(lane, r);
+            if (lr < mrows && gc < kw) Prow[(int64_t)lr * ldp + gc] = acc[c][r];
+        }
+    }
+    STAMP(12);
 }
 
 }  // namespace
@@ -199,40 +441,30 @@ static int panel_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info,
                        T* b, int64_t m, int64_t ldb, hipStream_t st)
 {
     const char* fn = FACTOR ? "cimrgp_potrf" : "cimrgp_trsm_rows";
+    const bool rows = (b != nullptr && m > 0);
     for (int64_t k0 = 0; k0 < n; k0 += CIMRGP_NB) {
         const int64_t w = (n - k0 < CIMRGP_NB) ? (n - k0) : CIMRGP_NB;
         const int64_t k1 = k0 + w;
         for (int64_t c0 = k0; c0 < k1; c0 += SB) {
             const int sw = (int)((k1 - c0 < SB) ? (k1 - c0) : SB);
-            const int64_t pc = c0 + sw;            // first column/row after this sub-block
+            const int kprev = (int)(c0 - k0);
+            const int64_t pc = c0 + sw;            // first row after this sub-block
             T* inv = ws + (c0 / SB) * (SB * SB);
+            const T* lrow = kmat + c0 * ld + k0;   // rows of the diagonal block, earlier panel columns
             if (FACTOR) {
                 hipLaunchKernelGGL((k_diag64<T>), dim3(1), dim3(256), 0, st,
-                                   kmat + c0 * ld + c0, ld, sw, inv, info, (int)c0);
-                CIMRGP_LAUNCH_CHECK(fn);
-                if (n > pc) {
-                    hipLaunchKernelGGL((k_trsm64<T>), dim3((unsigned)((n - pc + SB - 1) / SB)), dim3(256), 0, st,
-                                       kmat + pc * ld + c0, ld, (int)(n - pc), sw, (const T*)inv);
-                    CIMRGP_LAUNCH_CHECK(fn);
-                }
-            }
-            if (b != nullptr && m > 0) {
-                hipLaunchKernelGGL((k_trsm64<T>), dim3((unsigned)((m + SB - 1) / SB)), dim3(256), 0, st,
-                                   b + c0, ldb, (int)m, sw, (const T*)inv);
+                                   kmat + c0 * ld + c0, ld, sw, lrow, kprev, inv, info, (int)c0);
                 CIMRGP_LAUNCH_CHECK(fn);
             }
-            const int64_t pw = k1 - pc;            // panel columns still to update
-            if (pw > 0) {
-                if (FACTOR) {
-                    int rc = gemm_nt_sub<T>(kmat + pc * ld + pc, ld, kmat + pc * ld + c0, ld,
-                                            kmat + pc * ld + c0, ld, n - pc, pw, sw, false, st);
-                    if (rc) return rc;
-                }
-                if (b != nullptr && m > 0) {
-                    int rc = gemm_nt_sub<T>(b + pc, ldb, b + c0, ldb, kmat + pc * ld + c0, ld,
-                                            m, pw, sw, false, st);
-                    if (rc) return rc;
-                }
+            const int64_t m1 = FACTOR ? (n - pc) : 0;
+            const int nb1 = (int)((m1 + TR - 1) / TR);
+            const int nb2 = rows ? (int)((m + TR - 1) / TR) : 0;
+            if (nb1 + nb2 > 0) {
+                hipLaunchKernelGGL((k_trsm64<T>), dim3((unsigned)(nb1 + nb2)), dim3(256), 0, st,
+                                   kmat + pc * ld + c0, ld, (int)m1, nb1,
+                                   rows ? b + c0 : nullptr, ldb, rows ? (int)m : 0,
+                                   sw, kprev, lrow, ld, (const T*)inv);
+                CIMRGP_LAUNCH_CHECK(fn);
             }
         }
         if (n > k1) {
@@ -241,10 +473,10 @@ static int panel_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info,
                 TrailRec* rec = rec_open(st, mm * (mm + 1.0) * (double)w);   // lower SYRK: M(M+1)K flop
                 int rc = gemm_nt_sub<T>(kmat + k1 * ld + k1, ld, kmat + k1 * ld + k0, ld,
                                         kmat + k1 * ld + k0, ld, n - k1, n - k1, (int)w, true, st);
-                if (rec) hipEventRecord(rec->stop, st);
+                if (rec) (void)hipEventRecord(rec->stop, st);
                 if (rc) return rc;
             }
-            if (b != nullptr && m > 0) {
+            if (rows) {
                 int rc = gemm_nt_sub<T>(b + k1, ldb, b + k0, ldb, kmat + k1 * ld + k0, ld,
                                         m, n - k1, (int)w, false, st);
                 if (rc) return rc;
@@ -254,12 +486,122 @@ static int panel_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info,
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Factorisation with one-panel look-ahead.  The trailing update of panel p is
+// split into the columns of panel p+1 ("head", rectangular) and the rest (lower
+// SYRK).  As soon as the head is done, panel p+1 is factored on a second,
+// high-priority stream while the main stream is still busy with the rest; the
+// latency-bound panel chain (64 sequential columns per diagonal block) hides
+// behind the MFMA-bound update for as long as the trailing matrix is large.
+// Fork/join by events only (graph-capturable); the side stream and the event
+// pool are created once per device and reused.
+// ---------------------------------------------------------------------------
+namespace {
+struct LookAhead {
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> ev;
+    int device = -1;
+};
+LookAhead g_la[16];
+
+LookAhead* lookahead_ctx(size_t nevents)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    LookAhead& la = g_la[dev];
+    if (la.side == nullptr) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&la.side, hipStreamNonBlocking, hi) != hipSuccess) { la.side = nullptr; return nullptr; }
+        la.device = dev;
+    }
+    while (la.ev.size() < nevents) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        la.ev.push_back(e);
+    }
+    return &la;
+}
+
+template <typename T>
+int factor_panel(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, int64_t k0, int64_t w, hipStream_t st)
+{
+    const char* fn = "cimrgp_potrf";
+    const int64_t k1 = k0 + w;
+    for (int64_t c0 = k0; c0 < k1; c0 += SB) {
+        const int sw = (int)((k1 - c0 < SB) ? (k1 - c0) : SB);
+        const int kprev = (int)(c0 - k0);
+        const int64_t pc = c0 + sw;
+        T* inv = ws + (c0 / SB) * (SB * SB);
+        const T* lrow = kmat + c0 * ld + k0;
+        hipLaunchKernelGGL((k_diag64<T>), dim3(1), dim3(256), 0, st,
+                           kmat + c0 * ld + c0, ld, sw, lrow, kprev, inv, info, (int)c0);
+        CIMRGP_LAUNCH_CHECK(fn);
+        const int64_t m1 = n - pc;
+        const int nb1 = (int)((m1 + TR - 1) / TR);
+        if (nb1 > 0) {
+            hipLaunchKernelGGL((k_trsm64<T>), dim3((unsigned)nb1), dim3(256), 0, st,
+                               kmat + pc * ld + c0, ld, (int)m1, nb1, (T*)nullptr, (int64_t)0, 0,
+                               sw, kprev, lrow, ld, (const T*)inv);
+            CIMRGP_LAUNCH_CHECK(fn);
+        }
+    }
+    return 0;
+}
+}  // namespace
+
+#define CIMRGP_HIP_TRY(call, what) \
+    do { hipError_t e__ = (call); if (e__ != hipSuccess) return check_hip(e__, "cimrgp_potrf", what); } while (0)
+
 template <typename T>
 int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, hipStream_t st)
 {
-    hipError_t e = hipMemsetAsync(info, 0, sizeof(int32_t), st);
-    if (e != hipSuccess) return check_hip(e, "cimrgp_potrf", "hipMemsetAsync(info)");
-    return panel_sweep<T, true>(k, n, ld, ws, info, nullptr, 0, 0, st);
+    CIMRGP_HIP_TRY(hipMemsetAsync(info, 0, sizeof(int32_t), st), "hipMemsetAsync(info)");
+    const int64_t npanels = (n + CIMRGP_NB - 1) / CIMRGP_NB;
+    LookAhead* la = (npanels > 2) ? lookahead_ctx((size_t)(2 * npanels + 2)) : nullptr;
+    if (la == nullptr) return panel_sweep<T, true>(k, n, ld, ws, info, nullptr, 0, 0, st);
+
+    hipStream_t sp = la->side;
+    size_t ne = 0;
+    int rc = factor_panel<T>(k, n, ld, ws, info, 0, (n < CIMRGP_NB) ? n : CIMRGP_NB, st);
+    if (rc) return rc;
+    bool side_pending = false;
+    hipEvent_t ev_panel = nullptr;
+    for (int64_t k0 = 0; k0 < n; k0 += CIMRGP_NB) {
+        const int64_t w  = (n - k0 < CIMRGP_NB) ? (n - k0) : CIMRGP_NB;
+        const int64_t k1 = k0 + w;
+        if (k1 >= n) break;
+        const int64_t wn = (n - k1 < CIMRGP_NB) ? (n - k1) : CIMRGP_NB;   // next panel
+        const int64_t k2 = k1 + wn;
+        if (side_pending) {                            // panel k0 was factored on the side stream
+            CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0), "hipStreamWaitEvent");
+            side_pending = false;
+        }
+        // head: columns of the next panel, all rows below
+        rc = gemm_nt_sub<T>(k + k1 * ld + k1, ld, k + k1 * ld + k0, ld, k + k1 * ld + k0, ld,
+                            n - k1, wn, (int)w, false, st);
+        if (rc) return rc;
+        hipEvent_t ev_head = la->ev[ne++];
+        CIMRGP_HIP_TRY(hipEventRecord(ev_head, st), "hipEventRecord");
+        // next panel on the side stream, concurrently with the rest of this update
+        CIMRGP_HIP_TRY(hipStreamWaitEvent(sp, ev_head, 0), "hipStreamWaitEvent");
+        rc = factor_panel<T>(k, n, ld, ws, info, k1, wn, sp);
+        if (rc) return rc;
+        ev_panel = la->ev[ne++];
+        CIMRGP_HIP_TRY(hipEventRecord(ev_panel, sp), "hipEventRecord");
+        side_pending = true;
+        // rest: lower SYRK beyond the next panel
+        if (n > k2) {
+            const double mm = (double)(n - k2);
+            TrailRec* rec = rec_open(st, mm * (mm + 1.0) * (double)w);
+            rc = gemm_nt_sub<T>(k + k2 * ld + k2, ld, k + k2 * ld + k0, ld, k + k2 * ld + k0, ld,
+                                n - k2, n - k2, (int)w, true, st);
+            if (rec) (void)hipEventRecord(rec->stop, st);
+            if (rc) return rc;
+        }
+    }
+    if (side_pending) CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0), "hipStreamWaitEvent");
+    return 0;
 }
 
 template <typename T>

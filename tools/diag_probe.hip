@@ -1,0 +1,66 @@
+// Diagnostic: phase stamps (s_memtime) of the panel kernels.  Not part of the product.
+#define CIMRGP_STAMP 1
+#include "../cimrgp_amd/csrc/potrf.hip"
+#include "../cimrgp_amd/csrc/gemm_nt.hip"
+#include "../cimrgp_amd/csrc/api.hip"
+#include <vector>
+#include <cmath>
+using namespace cimrgp;
+namespace cimrgp {
+template <typename T> int rbf_gram_run(const T*, int64_t, const T*, int64_t, int, double, double, double, T*, int64_t, bool, bool, hipStream_t) { return 0; }
+template <typename T> int predict_mean_run(const T*, int64_t, int, const T*, int, const T*, int64_t, double, double, const T*, T*, int, hipStream_t) { return 0; }
+template <typename T> int potrs_run(const T*, int64_t, int64_t, const T*, T*, int, T*, T*, hipStream_t) { return 0; }
+template <typename T> int predict_from_w_run(const T*, int64_t, int64_t, int64_t, const T*, int, double, double, const T*, T*, T*, int, hipStream_t) { return 0; }
+template <typename T> int misc_block_stats(const T*, const T*, int64_t, int, T*, hipStream_t) { return 0; }
+template <typename T> int misc_residual(const T*, const T*, const T*, int64_t, int, T*, hipStream_t) { return 0; }
+template <typename T> int misc_train_mean(const T*, const T*, const T*, const T*, int64_t, int, T*, int, hipStream_t) { return 0; }
+template <typename T> int misc_add_diag(T*, int64_t, int64_t, const T*, hipStream_t) { return 0; }
+template <typename T> int misc_noise_from_stats(const T*, int, double, double, T*, hipStream_t) { return 0; }
+template <typename T> int misc_logdet_half(const T*, int64_t, int64_t, double*, hipStream_t) { return 0; }
+}
+int main()
+{
+    const int n = 2048, ld = 2048;
+    std::vector<double> h((size_t)n * ld, 0.0);
+    for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) h[(size_t)i * ld + j] = std::exp(-0.5 * (i - j) * (i - j) / 900.0) + (i == j ? 0.01 : 0.0);
+    double *dK, *dws; int32_t* dinfo;
+    hipMalloc(&dK, h.size() * 8); hipMalloc(&dws, (n / 64) * 64 * 64 * 8); hipMalloc(&dinfo, 4);
+    hipMemcpy(dK, h.data(), h.size() * 8, hipMemcpyHostToDevice); hipMemset(dinfo, 0, 4);
+    long long st[32];
+    for (int kprev = 0; kprev <= 192; kprev += 64) {
+        for (int rep = 0; rep < 2; ++rep) {
+            hipLaunchKernelGGL((k_diag64<double>), dim3(1), dim3(256), 0, 0, dK + (size_t)256 * ld + 256, (int64_t)ld, 64, dK + (size_t)256 * ld + 256 - kprev, kprev, dws, dinfo, 0);
+            hipDeviceSynchronize();
+            hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamp), sizeof(st));
+            if (rep) printf("diag64 kprev=%3d: load %lld  mfma %lld  loop %lld  store %lld  total %lld ticks (%.1f us @2.35GHz)\n", kprev, st[1]-st[0], st[2]-st[1], st[3]-st[2], st[4]-st[3], st[4]-st[0], (st[4]-st[0])/2350.0);
+        }
+    }
+    for (int kprev = 0; kprev <= 192; kprev += 64) {
+        for (int rep = 0; rep < 2; ++rep) {
+            hipLaunchKernelGGL((k_trsm64<double>), dim3(32), dim3(256), 0, 0, dK + (size_t)512 * ld + 256, (int64_t)ld, 1024, 16, (double*)nullptr, (int64_t)0, 0, 64, kprev, dK + (size_t)256 * ld + 256 - kprev, (int64_t)ld, dws);
+            hipDeviceSynchronize();
+            hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamp), sizeof(st));
+            if (rep) printf("trsm64 kprev=%3d: kloop %lld  stage %lld  mma %lld  store %lld  total %lld ticks (%.1f us)\n", kprev, st[9]-st[8], st[10]-st[9], st[11]-st[10], st[12]-st[11], st[12]-st[8], (st[12]-st[8])/2350.0);
+        }
+    }
+    // trailing-update kernel: one workgroup alone, then a full grid
+    {
+        const int nn = 8192; const int64_t l2 = 8192;
+        double* dA; hipMalloc(&dA, (size_t)nn * l2 * 8); hipMemset(dA, 0, (size_t)nn * l2 * 8);
+        for (int cfg = 0; cfg < 4; ++cfg) {
+            const int M = (cfg == 0) ? 128 : (cfg == 1 ? 2048 : 7936);
+            const bool lower = cfg != 3;
+            for (int rep = 0; rep < 2; ++rep) {
+                hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+                hipEventRecord(e0);
+                gemm_nt_sub<double>(dA + 256 * l2 + 256, l2, dA + 256 * l2, l2, dA + 256 * l2, l2, M, lower ? M : 256, 256, lower, 0);
+                hipEventRecord(e1); hipDeviceSynchronize();
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamp), sizeof(st));
+                if (rep) printf("gemm M=%d %s: prologue %lld  kloop %lld (%.0f/ktile)  epilogue %lld  total %lld ticks (%.1f us); kernel %.1f us\n", M, lower ? "lower" : "rect N=256",
+                                st[17]-st[16], st[18]-st[17], (st[18]-st[17])/16.0, st[19]-st[18], st[19]-st[16], (st[19]-st[16])/2350.0, ms*1e3);
+            }
+        }
+    }
+    return 0;
+}
