@@ -20,16 +20,16 @@ namespace cimrgp {
 
 namespace {
 
-constexpr int GT       = 128;            // tile edge (rows of A-tile = rows of B-tile)
 constexpr int KT_BYTES = 128;            // K bytes per row per stage
 constexpr int LROW     = KT_BYTES + 16;  // LDS row stride
-constexpr int OP_BYTES = GT * LROW;      // one operand, one stage
-constexpr int SMEM     = 4 * OP_BYTES;   // {A,B} x 2 stages = 73,728 B
+// W = MFMA tiles per wave and direction: W = 4 -> 128 x 128 workgroup tile (the trailing
+// update: 73,728 B of LDS, 2 workgroups per CU), W = 2 -> 64 x 64 tile (thin updates such as
+// the look-ahead "head", where a 128-tile grid would leave half of the CUs empty).
 
 // EDGE = false: M, N multiples of 128 and K a multiple of the stage depth -- no bounds logic
 // at all (every select on a prefetched register makes hipcc wait for it right behind the
 // load).  EDGE = true: ragged sizes, zero-fill and predicated stores.
-template <typename T, bool LOWER, bool EDGE>
+template <typename T, bool LOWER, bool EDGE, int W>
 __global__ __launch_bounds__(256, 2)
 void k_gemm_nt_sub(T* __restrict__ C, int64_t ldc,
                    const T* __restrict__ A, int64_t lda,
@@ -39,7 +39,10 @@ void k_gemm_nt_sub(T* __restrict__ C, int64_t ldc,
     using X = Mx<T>;
     using acc_t = typename X::acc_t;
     constexpr int BKE = KT_BYTES / (int)sizeof(T);
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    constexpr int GT = 32 * W;               // tile edge
+    constexpr int NP = GT / 32;              // staging passes (32 rows each)
+    constexpr int OP_BYTES = GT * LROW;      // one operand, one stage
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * OP_BYTES];
 
     int ti, tj;
     if (LOWER) {
@@ -66,12 +69,12 @@ void k_gemm_nt_sub(T* __restrict__ C, int64_t ldc,
 
     // Staging addresses: uniform tile base (SGPRs) + one 32-bit per-thread element offset per
     // operand row group, so the 8 loads of a stage need 8 VGPRs of addressing, not 16.
-    bool a_ok[4], b_ok[4];
-    int a_off_e[4], b_off_e[4];
+    bool a_ok[NP], b_ok[NP];
+    int a_off_e[NP], b_off_e[NP];
     const T* a_tile = A + (int64_t)row0 * lda;
     const T* b_tile = B + (int64_t)col0 * ldb;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < NP; ++p) {
         const int r = sr + 32 * p;
         a_ok[p] = (row0 + r) < M;
         b_ok[p] = (col0 + r) < N;
@@ -79,7 +82,7 @@ void k_gemm_nt_sub(T* __restrict__ C, int64_t ldc,
         b_off_e[p] = ((EDGE && !b_ok[p]) ? 0 : r) * (int)ldb + sc * X::EPC;
     }
 
-    uint4 ra[4], rb[4];
+    uint4 ra[NP], rb[NP];
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
 
     // GLOAD only ISSUES the loads (clamped, always valid addresses); every use of the loaded
@@ -92,7 +95,7 @@ void k_gemm_nt_sub(T* __restrict__ C, int64_t ldc,
     {                                                                            \
         const int kcol = (kt_) * BKE + sc * X::EPC;                              \
         const int koff = (!EDGE || kcol < K) ? (kt_) * BKE : 0;                  \
-        _Pragma("unroll") for (int p = 0; p < 4; ++p) {                          \
+        _Pragma("unroll") for (int p = 0; p < NP; ++p) {                         \
             ra[p] = *reinterpret_cast<const uint4*>(a_tile + (a_off_e[p] + koff)); \
             rb[p] = *reinterpret_cast<const uint4*>(b_tile + (b_off_e[p] + koff)); \
         }                                                                        \
@@ -104,7 +107,7 @@ void k_gemm_nt_sub(T* __restrict__ C, int64_t ldc,
         const int kcol = (kt_) * BKE + sc * X::EPC;                              \
         const bool kin = kcol < K;                                               \
         const bool kfull = kcol + X::EPC <= K;                                   \
-        _Pragma("unroll") for (int p = 0; p < 4; ++p) {                          \
+        _Pragma("unroll") for (int p = 0; p < NP; ++p) {                         \
             uint4 va = ra[p], vb = rb[p];                                        \
             if (EDGE) {                                                          \
                 if (!(a_ok[p] && kin)) va = zero4;                               \
@@ -117,8 +120,8 @@ void k_gemm_nt_sub(T* __restrict__ C, int64_t ldc,
     }
 
     const int frow = lane & 15, fslot = lane >> 4;
-    const unsigned a_off = (unsigned)((wr * 64 + frow) * LROW + fslot * 8);
-    const unsigned b_off = (unsigned)((wc * 64 + frow) * LROW + fslot * 8);
+    const unsigned a_off = (unsigned)((wr * 16 * W + frow) * LROW + fslot * 8);
+    const unsigned b_off = (unsigned)((wc * 16 * W + frow) * LROW + fslot * 8);
 
     STAMP(16);
     CIMRGP_GLOAD(0);
@@ -127,15 +130,15 @@ void k_gemm_nt_sub(T* __restrict__ C, int64_t ldc,
     // together with the first operand tiles, and the epilogue is stores only.  (A read-modify-
     // write epilogue serialises 64 dependent load->store round trips per lane.)
     const bool diag_tile = LOWER && (ti == tj);
-    acc_t acc[4][4];
+    acc_t acc[W][W];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
+    for (int mi = 0; mi < W; ++mi) {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int gc = col0 + wc * 64 + ni * 16 + (lane & 15);
+        for (int ni = 0; ni < W; ++ni) {
+            const int gc = col0 + wc * 16 * W + ni * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int gr = row0 + wr * 64 + mi * 16 + X::crow(lane, r);
+                const int gr = row0 + wr * 16 * W + mi * 16 + X::crow(lane, r);
                 // unconditional load from a clamped (always valid) address, then select
                 if (EDGE) {
                     const T v = C[(int64_t)min(gr, M - 1) * ldc + min(gc, N - 1)];
@@ -150,9 +153,9 @@ void k_gemm_nt_sub(T* __restrict__ C, int64_t ldc,
     // Make the C loads complete HERE: otherwise hipcc guards the first MFMA of every loop
     // iteration with s_waitcnt vmcnt(0), which also drains the operand prefetch just issued.
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < W; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) asm volatile("" : "+v"(acc[mi][ni]));
+        for (int ni = 0; ni < W; ++ni) asm volatile("" : "+v"(acc[mi][ni]));
     __syncthreads();
     STAMP(17);
 
@@ -163,17 +166,17 @@ void k_gemm_nt_sub(T* __restrict__ C, int64_t ldc,
         const unsigned char* bs = as + OP_BYTES;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            uint2 a[4], b[4];
+            uint2 a[W], b[W];
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < W; ++mi)
                 a[mi] = X::neg(*reinterpret_cast<const uint2*>(as + a_off + mi * 16 * LROW + s * 32));
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < W; ++ni)
                 b[ni] = *reinterpret_cast<const uint2*>(bs + b_off + ni * 16 * LROW + s * 32);
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < W; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = X::mma(a[mi], b[ni], acc[mi][ni]);
+                for (int ni = 0; ni < W; ++ni) acc[mi][ni] = X::mma(a[mi], b[ni], acc[mi][ni]);
         }
         if (more) CIMRGP_SWRITE((kt + 1) & 1, kt + 1);
         __syncthreads();
@@ -186,13 +189,13 @@ void k_gemm_nt_sub(T* __restrict__ C, int64_t ldc,
     asm volatile("" : "+s"(Mv), "+s"(Nv));      // recompute the store predicates here (not hoisted over the loop)
     // epilogue: store the tile (f64 map: 16 lanes x 8 B = one 128-byte line per row)
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
+    for (int mi = 0; mi < W; ++mi) {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int gc = col0 + wc * 64 + ni * 16 + (lane & 15);
+        for (int ni = 0; ni < W; ++ni) {
+            const int gc = col0 + wc * 16 * W + ni * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int gr = row0 + wr * 64 + mi * 16 + X::crow(lane, r);
+                const int gr = row0 + wr * 16 * W + mi * 16 + X::crow(lane, r);
                 if ((!EDGE || (gr < Mv && gc < Nv)) && (!diag_tile || gc <= gr)) C[(int64_t)gr * ldc + gc] = acc[mi][ni][r];
             }
         }
@@ -201,6 +204,26 @@ void k_gemm_nt_sub(T* __restrict__ C, int64_t ldc,
 }
 
 }  // namespace
+
+template <typename T, int W>
+static int gemm_launch(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t ldb,
+                       int64_t m, int64_t n, int k, bool lower, hipStream_t st)
+{
+    const char* fn = "gemm_nt_sub";
+    constexpr int GT = 32 * W;
+    const int64_t tm = (m + GT - 1) / GT, tn = (n + GT - 1) / GT;
+    const bool edge = (m % GT) != 0 || (n % GT) != 0 || (k % (KT_BYTES / (int)sizeof(T))) != 0;
+    const int64_t tiles = lower ? tm * (tm + 1) / 2 : tm * tn;
+    CIMRGP_REQUIRE(tiles < (1ll << 31), fn, "grid too large");
+#define CIMRGP_GEMM_GO(LO_, ED_)                                                                   \
+    hipLaunchKernelGGL((k_gemm_nt_sub<T, LO_, ED_, W>), dim3((unsigned)tiles), dim3(256), 0, st,  \
+                       c, ldc, a, lda, b, ldb, (int)m, (int)n, k, (int)tn)
+    if (lower) { if (edge) CIMRGP_GEMM_GO(true, true);  else CIMRGP_GEMM_GO(true, false); }
+    else       { if (edge) CIMRGP_GEMM_GO(false, true); else CIMRGP_GEMM_GO(false, false); }
+#undef CIMRGP_GEMM_GO
+    CIMRGP_LAUNCH_CHECK(fn);
+    return 0;
+}
 
 template <typename T>
 int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t ldb,
@@ -211,26 +234,11 @@ int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t 
     CIMRGP_REQUIRE(m < (1ll << 30) && n < (1ll << 30), fn, "matrix too large");
     CIMRGP_REQUIRE(aligned16(a) && aligned16(b), fn, "operand base not 16-byte aligned");
     CIMRGP_REQUIRE(lda % Mx<T>::EPC == 0 && ldb % Mx<T>::EPC == 0, fn, "leading dimension not a multiple of 16 bytes");
-    const int64_t tm = (m + GT - 1) / GT, tn = (n + GT - 1) / GT;
-    const bool edge = (m % GT) != 0 || (n % GT) != 0 || (k % (KT_BYTES / (int)sizeof(T))) != 0;
-    if (lower) {
-        CIMRGP_REQUIRE(m == n, fn, "lower update needs a square C");
-        const int64_t tiles = tm * (tm + 1) / 2;
-        CIMRGP_REQUIRE(tiles < (1ll << 31), fn, "grid too large");
-        if (edge) hipLaunchKernelGGL((k_gemm_nt_sub<T, true, true>), dim3((unsigned)tiles), dim3(256), 0, st,
-                                     c, ldc, a, lda, b, ldb, (int)m, (int)n, k, (int)tn);
-        else      hipLaunchKernelGGL((k_gemm_nt_sub<T, true, false>), dim3((unsigned)tiles), dim3(256), 0, st,
-                                     c, ldc, a, lda, b, ldb, (int)m, (int)n, k, (int)tn);
-    } else {
-        const int64_t tiles = tm * tn;
-        CIMRGP_REQUIRE(tiles < (1ll << 31), fn, "grid too large");
-        if (edge) hipLaunchKernelGGL((k_gemm_nt_sub<T, false, true>), dim3((unsigned)tiles), dim3(256), 0, st,
-                                     c, ldc, a, lda, b, ldb, (int)m, (int)n, k, (int)tn);
-        else      hipLaunchKernelGGL((k_gemm_nt_sub<T, false, false>), dim3((unsigned)tiles), dim3(256), 0, st,
-                                     c, ldc, a, lda, b, ldb, (int)m, (int)n, k, (int)tn);
-    }
-    CIMRGP_LAUNCH_CHECK(fn);
-    return 0;
+    CIMRGP_REQUIRE(!lower || m == n, fn, "lower update needs a square C");
+    // fewer than ~2 workgroups per CU with 128-tiles: use 64-tiles (4x the workgroups, 1/4 the work each)
+    const int64_t t128 = ((m + 127) / 128) * ((n + 127) / 128) / (lower ? 2 : 1);
+    if (t128 < 512) return gemm_launch<T, 2>(c, ldc, a, lda, b, ldb, m, n, k, lower, st);
+    return gemm_launch<T, 4>(c, ldc, a, lda, b, ldb, m, n, k, lower, st);
 }
 
 template int gemm_nt_sub<double>(double*, int64_t, const double*, int64_t, const double*, int64_t,

@@ -287,41 +287,46 @@ void k_diag64(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow, 
     for (int e = tid; e < SB * SB; e += 256) iout[e] = (T)0;
     STAMP(2);
 
+    // Column j+1 is published as soon as its own entries have been updated at pivot j -- before
+    // the other 15 register slots -- so the LDS store/barrier latency of the next pivot overlaps
+    // the rest of this pivot's update (software pipelining of the publish).
+    if (g == 0) comb[0][i] = a[0];                   // column 0
     for (int gg = 0; gg < 4; ++gg) {
 #pragma unroll
         for (int u0 = 0; u0 < 16; ++u0) {
             const int j = 16 * gg + u0;
             if (j < w) {                             // uniform
-                T* cb = comb[j & 1];
-                if (g == gg) cb[i] = a[u0];          // the whole column j of A in one store
+                const T* cb = comb[j & 1];
+                T* cbn = comb[(j + 1) & 1];
                 lds_barrier();
                 if (g >= gg) {
                     const T d  = cb[j];
                     const T ci = cb[i];
                     const T r  = rsqrt_refined<T>(d);
                     const T h  = (i == j) ? r : ci * r;
-                    if (g == gg) {
+                    const T nhr = -h * r;            // A[i][k] -= A[k][j] * (h r)
+                    const bool pivot_row = (i == j);
+                    if (g > gg) {
+                        // slot 0 first: if this wave owns column j+1 (u0 == 15, g == gg + 1) it is the next pivot
+                        a[0] = fma(nhr, cb[16 * g], pivot_row ? (T)0 : a[0]);
+                        if (u0 == 15 && g == gg + 1) cbn[i] = a[0];
+#pragma unroll
+                        for (int u = 1; u < 16; ++u)
+                            a[u] = fma(nhr, cb[16 * g + u], pivot_row ? (T)0 : a[u]);
+                    } else {
+                        if (u0 < 15) {               // next pivot column lives in this wave, slot u0 + 1
+                            a[u0 + 1] = fma(nhr, cb[16 * g + u0 + 1], pivot_row ? (T)0 : a[u0 + 1]);
+                            cbn[i] = a[u0 + 1];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) {
+                            if (u > u0 + 1)
+                                a[u] = fma(nhr, cb[16 * g + u], pivot_row ? (T)0 : a[u]);
+                        }
                         if (!(d > (T)0) && i == j) atomicCAS(info, 0, col_base + j + 1);
                         if (i >= j) lout[i * LS + j] = (i == j) ? d * r : h;
                         else        iout[j * SB + i] = h;
                         if (i == j) iout[j * SB + j] = r;
-                    }
-                    const T nhr = -h * r;            // A[i][k] -= A[k][j] * (h r)
-                    const bool pivot_row = (i == j);
-                    if (g > gg) {
-#pragma unroll
-                        for (int u = 0; u < 16; ++u) {
-                            const T base = pivot_row ? (T)0 : a[u];
-                            a[u] = fma(nhr, cb[16 * g + u], base);
-                        }
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < 16; ++u) {
-                            if (u > u0) {
-                                const T base = pivot_row ? (T)0 : a[u];
-                                a[u] = fma(nhr, cb[16 * g + u], base);
-                            }
-                        }
                     }
                 }
             }
@@ -350,10 +355,9 @@ void k_diag64(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow, 
 constexpr int TR = 32;   // rows per workgroup of the panel solve
 
 template <typename T>
-__global__ __launch_bounds__(256)
-void k_trsm64(T* __restrict__ P1, int64_t ld1, int M1, int nb1,
-              T* __restrict__ P2, int64_t ld2, int M2,
-              int kw, int kprev, const T* __restrict__ Lrow, int64_t ldl, const T* __restrict__ invL)
+static __device__ __forceinline__ void trsm64_body(T* __restrict__ Prow, int64_t ldp, int mrows, int kw, int kprev,
+                                                    const T* __restrict__ Lrow, int64_t ldl,
+                                                    const T* __restrict__ invL)
 {
     using X = Mx<T>;
     using TL = Tile64<T>;
@@ -367,13 +371,6 @@ void k_trsm64(T* __restrict__ P1, int64_t ld1, int M1, int nb1,
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rt = wave & 1, ch = wave >> 1;
-    const bool second = (int)blockIdx.x >= nb1;
-    T* P = second ? P2 : P1;
-    const int64_t ldp = second ? ld2 : ld1;
-    const int M = second ? M2 : M1;
-    const int row0 = (second ? (int)blockIdx.x - nb1 : (int)blockIdx.x) * TR;
-    const int mrows = min(TR, M - row0);
-    T* Prow = P + (int64_t)row0 * ldp;           // columns of this sub-block
     const T* Pprev = Prow - kprev;               // the panel's earlier columns of the same rows
 
     STAMP(8);
@@ -429,6 +426,48 @@ void k_trsm64(T* __restrict__ P1, int64_t ld1, int M1, int nb1,
         }
     }
     STAMP(12);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256)
+void k_trsm64(T* __restrict__ P1, int64_t ld1, int M1, int nb1,
+              T* __restrict__ P2, int64_t ld2, int M2,
+              int kw, int kprev, const T* __restrict__ Lrow, int64_t ldl, const T* __restrict__ invL)
+{
+    const bool second = (int)blockIdx.x >= nb1;
+    T* P = second ? P2 : P1;
+    const int64_t ldp = second ? ld2 : ld1;
+    const int M = second ? M2 : M1;
+    const int row0 = (second ? (int)blockIdx.x - nb1 : (int)blockIdx.x) * TR;
+    trsm64_body<T>(P + (int64_t)row0 * ldp, ldp, min(TR, M - row0), kw, kprev, Lrow, ldl, invL);
+}
+
+// ---------------------------------------------------------------------------
+// 256x256 inverses of the diagonal blocks, for the skinny solves: the identity is
+// carried through the panel solve, batched over ALL panels (blockIdx.y), one launch
+// per 64-column sub-step:  invT_p = I L_pp^-T = (L_pp^-1)^T  (upper triangular,
+// row r = column r of L_pp^-1), stored 256 x 256 row-major per panel.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void k_invT_init(T* __restrict__ invT, int n)
+{
+    const int p = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;          // element of the 256 x 256 block
+    const int r = e >> 8, c = e & 255;
+    const int w = min(CIMRGP_NB, n - p * CIMRGP_NB);
+    invT[(int64_t)p * (CIMRGP_NB * CIMRGP_NB) + e] = (r == c && r < w) ? (T)1 : (T)0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256)
+void k_invT_step(T* __restrict__ invT, const T* __restrict__ L, int64_t ld, int n, const T* __restrict__ inv64, int s)
+{
+    const int p = blockIdx.y;
+    const int k0 = p * CIMRGP_NB, c0 = k0 + SB * s;
+    const int kw = min(SB, n - c0);
+    if (kw <= 0) return;
+    T* Prow = invT + (int64_t)p * (CIMRGP_NB * CIMRGP_NB) + (int64_t)blockIdx.x * TR * CIMRGP_NB + SB * s;
+    trsm64_body<T>(Prow, CIMRGP_NB, TR, kw, SB * s, L + (int64_t)c0 * ld + k0, ld, inv64 + (int64_t)(c0 / SB) * (SB * SB));
 }
 
 }  // namespace
@@ -550,6 +589,23 @@ int factor_panel(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, int64_t k
 }
 }  // namespace
 
+// Workspace layout: [ceil(n/64) slabs of 64x64 inverses][ceil(n/256) blocks of 256x256 invT].
+template <typename T>
+static int build_invT(const T* kmat, int64_t n, int64_t ld, T* ws, hipStream_t st)
+{
+    const char* fn = "cimrgp_potrf";
+    const int64_t nslab = (n + SB - 1) / SB, npan = (n + CIMRGP_NB - 1) / CIMRGP_NB;
+    T* invT = ws + nslab * (SB * SB);
+    hipLaunchKernelGGL((k_invT_init<T>), dim3(CIMRGP_NB * CIMRGP_NB / 256, (unsigned)npan), dim3(256), 0, st, invT, (int)n);
+    CIMRGP_LAUNCH_CHECK(fn);
+    for (int s = 0; s < CIMRGP_NB / SB; ++s) {
+        hipLaunchKernelGGL((k_invT_step<T>), dim3(CIMRGP_NB / TR, (unsigned)npan), dim3(256), 0, st,
+                           invT, kmat, ld, (int)n, (const T*)ws, s);
+        CIMRGP_LAUNCH_CHECK(fn);
+    }
+    return 0;
+}
+
 #define CIMRGP_HIP_TRY(call, what) \
     do { hipError_t e__ = (call); if (e__ != hipSuccess) return check_hip(e__, "cimrgp_potrf", what); } while (0)
 
@@ -559,7 +615,10 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, hipStream_t st)
     CIMRGP_HIP_TRY(hipMemsetAsync(info, 0, sizeof(int32_t), st), "hipMemsetAsync(info)");
     const int64_t npanels = (n + CIMRGP_NB - 1) / CIMRGP_NB;
     LookAhead* la = (npanels > 2) ? lookahead_ctx((size_t)(2 * npanels + 2)) : nullptr;
-    if (la == nullptr) return panel_sweep<T, true>(k, n, ld, ws, info, nullptr, 0, 0, st);
+    if (la == nullptr) {
+        int rc0 = panel_sweep<T, true>(k, n, ld, ws, info, nullptr, 0, 0, st);
+        return rc0 ? rc0 : build_invT<T>(k, n, ld, ws, st);
+    }
 
     hipStream_t sp = la->side;
     size_t ne = 0;
@@ -601,7 +660,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, hipStream_t st)
         }
     }
     if (side_pending) CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0), "hipStreamWaitEvent");
-    return 0;
+    return build_invT<T>(k, n, ld, ws, st);
 }
 
 template <typename T>

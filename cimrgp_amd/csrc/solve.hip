@@ -2,8 +2,8 @@
 // tail (row reductions over W = K(X*,X) L^-T).
 //
 // The skinny solves walk the 256-column panels: per panel ONE launch in which
-// every workgroup first solves the 256x256 diagonal block redundantly (four
-// sub-steps using the 64x64 inverses potrf left in the workspace, all from L2)
+// every workgroup first applies the stored 256x256 inverse of the diagonal block
+// (left in the workspace by potrf, L2-resident) redundantly, one memory round trip,
 // and then subtracts its slice of  L[rows below, panel] z_p  (forward) or
 // L[panel, columns left]^T a_p  (backward) from the running right-hand side.
 // Right-hand sides are kept "RHS-major" (q x n) so the updates are coalesced.
@@ -29,121 +29,76 @@ __global__ void k_transpose_nq(const T* __restrict__ src, T* __restrict__ dst, i
 }
 
 constexpr int PW = CIMRGP_NB;      // panel width of the skinny solves (256)
+constexpr int ST = 1024;           // threads per workgroup of the skinny solves
 
-// Sum the 4 per-wave partials held in LDS part[4][MAXQ][64] into one value per (c, t).
+// Deterministic sum of `parts` partial results held in LDS red[part][c][idx].
 // ---------------------------------------------------------------------------
 // Forward panel step:  z_p = L_pp^-1 w_p ;  w[rows below the panel] -= L[rows, panel] z_p.
-// Every workgroup first solves the 256-wide diagonal block redundantly (four
-// 64-wide sub-steps: row-dot with the already solved part, then a product with
-// the stored 64x64 inverse; everything comes from L2), workgroup 0 publishes it,
-// then each workgroup updates its own slice of rows (16 lanes per row, 4
-// elements per lane, coalesced 16-byte loads, all loads of a pass in flight).
+// Every workgroup first forms z_p itself from the stored 256x256 invT_p = (L_pp^-1)^T
+// (column-sum form: thread = column, 4-way split over the rows, all loads independent and
+// coalesced along the row; 512 KB per panel, L2-resident after the first workgroup),
+// workgroup 0 publishes it, then each workgroup updates 64 rows below the panel
+// (16 lanes per row, 16 contiguous elements per lane).
 // ---------------------------------------------------------------------------
-// dst[c][lr] (-)= sum_k M[lr][k] x[c][k]  for lr < nrows (<= 64), k < kw (<= 256): 16 lanes per
-// row, 4 contiguous elements per lane and 64-column segment, 16 rows per pass, every load of a
-// pass independent of the others (memory-level parallelism instead of a dependent chain).
-template <typename T, bool ASSIGN>
-static __device__ __forceinline__ void rowdot64(const T* __restrict__ M, int64_t ldm, int nrows, int kw,
-                                                 const T (*x)[CIMRGP_NB], int xoff, T (*dst)[CIMRGP_NB], int doff, int q)
-{
-    const int l16 = threadIdx.x & 15, slot = threadIdx.x >> 4;
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-        const int lr = slot + 16 * pass;
-        T sum[MAXQ];
-#pragma unroll
-        for (int c = 0; c < MAXQ; ++c) sum[c] = (T)0;
-        if (lr < nrows) {
-            const T* mp = M + (int64_t)lr * ldm;
-#pragma unroll
-            for (int seg = 0; seg < CIMRGP_NB / 64; ++seg) {
-                const int kk = seg * 64 + l16 * 4;
-                if (seg * 64 < kw) {
-                    T mv[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) mv[e] = (kk + e < kw) ? mp[kk + e] : (T)0;
-#pragma unroll
-                    for (int c = 0; c < MAXQ; ++c)
-                        if (c < q) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) sum[c] += mv[e] * x[c][xoff + kk + e];
-                        }
-                }
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < MAXQ; ++c) {
-            if (c < q) {
-                T sv = sum[c];
-                sv += __shfl_xor(sv, 8, 16);
-                sv += __shfl_xor(sv, 4, 16);
-                sv += __shfl_xor(sv, 2, 16);
-                sv += __shfl_xor(sv, 1, 16);
-                if (l16 == 0 && lr < nrows) {
-                    if (ASSIGN) dst[c][doff + lr] = sv;
-                    else        dst[c][doff + lr] -= sv;
-                }
-            }
-        }
-    }
-}
-
 template <typename T>
-__global__ __launch_bounds__(256)
-void k_fwd_panel(const T* __restrict__ L, int64_t ld, int n, const T* __restrict__ inv64,
-                 T* __restrict__ work, T* __restrict__ out, int q, int k0, int w, int rows_per_wg)
+__global__ __launch_bounds__(ST)
+void k_fwd_panel(const T* __restrict__ L, int64_t ld, int n, const T* __restrict__ invT,
+                 T* __restrict__ work, T* __restrict__ out, int q, int k0, int w)
 {
-    __shared__ T zs[MAXQ][PW];          // running right-hand side of the panel, then the solution
-    __shared__ T tmp[MAXQ][PW];
+    __shared__ T ws_[MAXQ][PW];         // right-hand side of the panel
+    __shared__ T zs[MAXQ][PW];          // solution of the panel
+    __shared__ T red[4][MAXQ][PW];
     const int tid = threadIdx.x;
-    for (int e = tid; e < q * PW; e += 256) {
+    for (int e = tid; e < q * PW; e += ST) {
         const int c = e / PW, u = e - c * PW;
-        zs[c][u] = (u < w) ? work[(int64_t)c * n + k0 + u] : (T)0;
+        ws_[c][u] = (u < w) ? work[(int64_t)c * n + k0 + u] : (T)0;
     }
     __syncthreads();
-    const int nsub = (w + SB - 1) / SB;
-    for (int s = 0; s < nsub; ++s) {
-        const int c0 = SB * s;
-        const int sw = min(SB, w - c0);
-        // rhs_s = zs_s - L[s-block rows, panel cols < c0] z[< c0]
-        if (c0 > 0) {
-            rowdot64<T, false>(L + (int64_t)(k0 + c0) * ld + k0, ld, sw, c0, zs, 0, zs, c0, q);
-            __syncthreads();
+    {
+        const int col = tid & (PW - 1), part = tid >> 8;          // 4 row parts of 64
+        const T* bp = invT + (int64_t)(k0 / PW) * (PW * PW) + col;
+        T acc[MAXQ];
+#pragma unroll
+        for (int c = 0; c < MAXQ; ++c) acc[c] = (T)0;
+        const int rbeg = part * 64;
+        if (rbeg <= col) {                                        // invT is upper triangular: rows <= col
+#pragma unroll 16
+            for (int r = rbeg; r < rbeg + 64; ++r) {
+                const T bv = bp[(int64_t)r * PW];
+#pragma unroll
+                for (int c = 0; c < MAXQ; ++c)
+                    if (c < q) acc[c] += bv * ws_[c][r];
+            }
         }
-        // z_s = I_s rhs_s   (through tmp: every row needs the whole rhs_s)
-        rowdot64<T, true>(inv64 + (int64_t)((k0 + c0) / SB) * (SB * SB), SB, sw, SB, zs, c0, tmp, c0, q);
-        __syncthreads();
-        for (int e = tid; e < q * SB; e += 256) {
-            const int c = e >> 6, u = e & 63;
-            const T v = (u < sw) ? tmp[c][c0 + u] : (T)0;
-            zs[c][c0 + u] = v;
-            if (blockIdx.x == 0 && u < sw) out[(int64_t)c * n + k0 + c0 + u] = v;
-        }
-        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < MAXQ; ++c)
+            if (c < q) red[part][c][col] = acc[c];
     }
-    // rows below the panel
+    __syncthreads();
+    for (int e = tid; e < q * PW; e += ST) {
+        const int c = e / PW, u = e - c * PW;
+        const T v = red[0][c][u] + red[1][c][u] + red[2][c][u] + red[3][c][u];
+        zs[c][u] = v;
+        if (blockIdx.x == 0 && u < w) out[(int64_t)c * n + k0 + u] = v;
+    }
+    __syncthreads();
+    // 64 rows below the panel per workgroup
     const int l16 = tid & 15, slot = tid >> 4;
-    const int rbeg = k0 + w + blockIdx.x * rows_per_wg;
-    const int rend = min(n, rbeg + rows_per_wg);
-#pragma unroll 4
-    for (int r = rbeg + slot; r < rend; r += 16) {
-        const T* lp = L + (int64_t)r * ld + k0;
+    const int r = k0 + w + blockIdx.x * 64 + slot;
+    if (r < n) {
+        const T* lp = L + (int64_t)r * ld + k0 + l16 * 16;
         T sum[MAXQ];
 #pragma unroll
         for (int c = 0; c < MAXQ; ++c) sum[c] = (T)0;
+        T lv[16];
 #pragma unroll
-        for (int seg = 0; seg < PW / 64; ++seg) {
-            const int kk = seg * 64 + l16 * 4;
-            T lv[4];
+        for (int e = 0; e < 16; ++e) lv[e] = (l16 * 16 + e < w) ? lp[e] : (T)0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) lv[e] = (kk + e < w) ? lp[kk + e] : (T)0;
+        for (int c = 0; c < MAXQ; ++c)
+            if (c < q) {
 #pragma unroll
-            for (int c = 0; c < MAXQ; ++c)
-                if (c < q) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) sum[c] += lv[e] * zs[c][kk + e];
-                }
-        }
+                for (int e = 0; e < 16; ++e) sum[c] += lv[e] * zs[c][l16 * 16 + e];
+            }
 #pragma unroll
         for (int c = 0; c < MAXQ; ++c) {
             if (c < q) {
@@ -159,100 +114,91 @@ void k_fwd_panel(const T* __restrict__ L, int64_t ld, int n, const T* __restrict
 }
 
 // ---------------------------------------------------------------------------
-// Backward panel step:  a_p = L_pp^-T w_p ;  w[cols left of the panel] -= L[panel, cols]^T a_p.
-// Column-sum form throughout (thread = column, coalesced along the row).
+// Backward panel step:  a_p = L_pp^-T w_p = invT_p w_p  (row-dot form) ;
+// w[cols left of the panel] -= L[panel, cols]^T a_p   (thread = column, 16-way split over
+// the panel's rows, 64 columns per workgroup).
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256)
-void k_bwd_panel(const T* __restrict__ L, int64_t ld, int n, const T* __restrict__ inv64,
+__global__ __launch_bounds__(ST)
+void k_bwd_panel(const T* __restrict__ L, int64_t ld, int n, const T* __restrict__ invT,
                  T* __restrict__ work, T* __restrict__ out, int q, int k0, int w)
 {
+    __shared__ T ws_[MAXQ][PW];
     __shared__ T zs[MAXQ][PW];
-    __shared__ T part[4][MAXQ][SB];
+    __shared__ T red[16][MAXQ][SB];
     const int tid = threadIdx.x;
-    const int t = tid & 63, pr = tid >> 6;
-    for (int e = tid; e < q * PW; e += 256) {
+    for (int e = tid; e < q * PW; e += ST) {
         const int c = e / PW, u = e - c * PW;
-        zs[c][u] = (u < w) ? work[(int64_t)c * n + k0 + u] : (T)0;
+        ws_[c][u] = (u < w) ? work[(int64_t)c * n + k0 + u] : (T)0;
     }
     __syncthreads();
-    const int nsub = (w + SB - 1) / SB;
-    for (int s = nsub - 1; s >= 0; --s) {
-        const int c0 = SB * s;
-        const int sw = min(SB, w - c0);
-        const int hi = c0 + sw;                       // solved part of the panel: [hi, w)
-        // (1) rhs_s[t] = zs[c0+t] - sum_{u in [hi, w)} L[k0+u][k0+c0+t] a[u]
-        T acc[MAXQ];
+    {
+        const int l16 = tid & 15, slot = tid >> 4;                // 64 rows per pass, 4 passes
+        const T* bp = invT + (int64_t)(k0 / PW) * (PW * PW);
 #pragma unroll
-        for (int c = 0; c < MAXQ; ++c) acc[c] = (T)0;
-        if (t < sw) {
-            const T* lp = L + (int64_t)k0 * ld + k0 + c0 + t;
-#pragma unroll 8
-            for (int u = hi + pr; u < w; u += 4) {
-                const T lv = lp[(int64_t)u * ld];
+        for (int pass = 0; pass < 4; ++pass) {
+            const int r = slot + 64 * pass;
+            const T* rp = bp + (int64_t)r * PW + l16 * 16;
+            T bv[16];
 #pragma unroll
-                for (int c = 0; c < MAXQ; ++c)
-                    if (c < q) acc[c] += lv * zs[c][u];
-            }
-        }
+            for (int e = 0; e < 16; ++e) bv[e] = rp[e];
+            T sum[MAXQ];
 #pragma unroll
-        for (int c = 0; c < MAXQ; ++c) part[pr][c][t] = acc[c];
-        __syncthreads();
-        if (pr == 0) {
+            for (int c = 0; c < MAXQ; ++c) sum[c] = (T)0;
 #pragma unroll
             for (int c = 0; c < MAXQ; ++c)
-                if (c < q) zs[c][c0 + t] -= part[0][c][t] + part[1][c][t] + part[2][c][t] + part[3][c][t];
-        }
-        __syncthreads();
-        // (2) a_s[t] = sum_{u >= t} I_s[u][t] rhs_s[u]
-        const T* ip = inv64 + (int64_t)((k0 + c0) / SB) * (SB * SB) + t;
+                if (c < q) {
 #pragma unroll
-        for (int c = 0; c < MAXQ; ++c) acc[c] = (T)0;
-#pragma unroll 8
-        for (int u = t + pr; u < sw; u += 4) {
-            const T iv = ip[u * SB];
-#pragma unroll
-            for (int c = 0; c < MAXQ; ++c)
-                if (c < q) acc[c] += iv * zs[c][c0 + u];
-        }
-#pragma unroll
-        for (int c = 0; c < MAXQ; ++c) part[pr][c][t] = acc[c];
-        __syncthreads();
-        if (pr == 0) {
+                    for (int e = 0; e < 16; ++e) sum[c] += bv[e] * ws_[c][l16 * 16 + e];
+                }
 #pragma unroll
             for (int c = 0; c < MAXQ; ++c) {
                 if (c < q) {
-                    const T v = part[0][c][t] + part[1][c][t] + part[2][c][t] + part[3][c][t];
-                    zs[c][c0 + t] = v;
-                    if (blockIdx.x == 0 && t < sw) out[(int64_t)c * n + k0 + c0 + t] = v;
+                    T sv = sum[c];
+                    sv += __shfl_xor(sv, 8, 16);
+                    sv += __shfl_xor(sv, 4, 16);
+                    sv += __shfl_xor(sv, 2, 16);
+                    sv += __shfl_xor(sv, 1, 16);
+                    if (l16 == 0) {
+                        zs[c][r] = sv;
+                        if (blockIdx.x == 0 && r < w) out[(int64_t)c * n + k0 + r] = sv;
+                    }
                 }
             }
         }
-        __syncthreads();
     }
-    // columns left of the panel: thread = column, 4-way split over the panel's rows
+    __syncthreads();
+    const int t = tid & 63, part = tid >> 6;                      // 16 row parts of 16
     const int col = blockIdx.x * SB + t;
     T acc[MAXQ];
 #pragma unroll
     for (int c = 0; c < MAXQ; ++c) acc[c] = (T)0;
     if (col < k0) {
         const T* lp = L + (int64_t)k0 * ld + col;
-        const int ubeg = pr * SB, uend = min(w, ubeg + SB);
-#pragma unroll 8
-        for (int u = ubeg; u < uend; ++u) {
-            const T lv = lp[(int64_t)u * ld];
+        const int ubeg = part * 16;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int u = ubeg + e;
+            const T lv = (u < w) ? lp[(int64_t)u * ld] : (T)0;
 #pragma unroll
             for (int c = 0; c < MAXQ; ++c)
                 if (c < q) acc[c] += lv * zs[c][u];
         }
     }
 #pragma unroll
-    for (int c = 0; c < MAXQ; ++c) part[pr][c][t] = acc[c];
+    for (int c = 0; c < MAXQ; ++c)
+        if (c < q) red[part][c][t] = acc[c];
     __syncthreads();
-    if (pr == 0 && col < k0) {
+    if (part == 0 && col < k0) {
 #pragma unroll
-        for (int c = 0; c < MAXQ; ++c)
-            if (c < q) work[(int64_t)c * n + col] -= part[0][c][t] + part[1][c][t] + part[2][c][t] + part[3][c][t];
+        for (int c = 0; c < MAXQ; ++c) {
+            if (c < q) {
+                T sv = (T)0;
+#pragma unroll
+                for (int pp = 0; pp < 16; ++pp) sv += red[pp][c][t];
+                work[(int64_t)c * n + col] -= sv;
+            }
+        }
     }
 }
 
@@ -317,13 +263,13 @@ int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* 
     const unsigned tg = (unsigned)((n * q + 255) / 256);
     hipLaunchKernelGGL((k_transpose_nq<T>), dim3(tg), dim3(256), 0, st, (const T*)rhs, work, n, q, 1);
     CIMRGP_LAUNCH_CHECK(fn);
-    const int rows_per_wg = 64;
+    const T* invT = ws + ((n + SB - 1) / SB) * (SB * SB);
     for (int64_t k0 = 0; k0 < n; k0 += PW) {
         const int w = (int)((n - k0 < PW) ? (n - k0) : PW);
         const int64_t below = n - (k0 + w);
-        const unsigned grid = (unsigned)((below + rows_per_wg - 1) / rows_per_wg);
-        hipLaunchKernelGGL((k_fwd_panel<T>), dim3(grid ? grid : 1), dim3(256), 0, st, l, ld, (int)n,
-                           ws, work, res, q, (int)k0, w, rows_per_wg);
+        const unsigned grid = (unsigned)((below + 63) / 64);
+        hipLaunchKernelGGL((k_fwd_panel<T>), dim3(grid ? grid : 1), dim3(ST), 0, st, l, ld, (int)n,
+                           invT, work, res, q, (int)k0, w);
         CIMRGP_LAUNCH_CHECK(fn);
     }
     if (z_out) {
@@ -336,8 +282,8 @@ int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* 
     for (int64_t k0 = last; k0 >= 0; k0 -= PW) {
         const int w = (int)((n - k0 < PW) ? (n - k0) : PW);
         const unsigned grid = (unsigned)((k0 + SB - 1) / SB);
-        hipLaunchKernelGGL((k_bwd_panel<T>), dim3(grid ? grid : 1), dim3(256), 0, st, l, ld, (int)n,
-                           ws, work, res, q, (int)k0, w);
+        hipLaunchKernelGGL((k_bwd_panel<T>), dim3(grid ? grid : 1), dim3(ST), 0, st, l, ld, (int)n,
+                           invT, work, res, q, (int)k0, w);
         CIMRGP_LAUNCH_CHECK(fn);
     }
     hipLaunchKernelGGL((k_transpose_nq<T>), dim3(tg), dim3(256), 0, st, (const T*)res, rhs, n, q, 0);

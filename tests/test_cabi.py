@@ -29,8 +29,9 @@ def test_library_exports_every_header_symbol():
 def test_version_and_workspace_size():
     lib = _lib.load()
     assert lib.cimrgp_version() >= 100
-    assert lib.cimrgp_potrf_workspace_bytes(_lib.F64, 8192) == 128 * 64 * 64 * 8
-    assert lib.cimrgp_potrf_workspace_bytes(_lib.F32, 65) == 2 * 64 * 64 * 4
+    # 64x64 inverse slabs + 256x256 inverse blocks of the diagonal
+    assert lib.cimrgp_potrf_workspace_bytes(_lib.F64, 8192) == (128 * 64 * 64 + 32 * 256 * 256) * 8
+    assert lib.cimrgp_potrf_workspace_bytes(_lib.F32, 65) == (2 * 64 * 64 + 1 * 256 * 256) * 4
     assert lib.cimrgp_potrf_workspace_bytes(_lib.F64, 0) == 0
 
 

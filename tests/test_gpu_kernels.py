@@ -85,12 +85,21 @@ def test_potrf_f64_matches_lapack(dev, n):
     assert rinfo == 0
     assert _relerr(lmat, ref) < 1e-10
     # the inverted 64x64 diagonal blocks left in the workspace
-    inv = ws.view(torch.float64).cpu().numpy().reshape(-1, 64, 64)
+    nslab, npan = (n + 63) // 64, (n + 255) // 256
+    flat = ws.view(torch.float64).cpu().numpy()
+    inv = flat[:nslab * 4096].reshape(-1, 64, 64)
     for s in range((n + 63) // 64):
         w = min(64, n - 64 * s)
         blk = ref[64 * s:64 * s + w, 64 * s:64 * s + w]
         np.testing.assert_allclose(inv[s][:w, :w] @ blk, np.eye(w), atol=1e-9)
         assert np.all(np.triu(inv[s], 1) == 0)
+    # the 256x256 blocks (L_pp^-1)^T the skinny solves use
+    inv_t = flat[nslab * 4096:nslab * 4096 + npan * 65536].reshape(npan, 256, 256)
+    for p in range(npan):
+        w = min(256, n - 256 * p)
+        blk = ref[256 * p:256 * p + w, 256 * p:256 * p + w]
+        np.testing.assert_allclose(inv_t[p][:w, :w].T @ blk, np.eye(w), atol=1e-8)
+        assert np.all(np.tril(inv_t[p], -1) == 0)
 
 
 @pytest.mark.parametrize("n", [64, 257, 1025])
