@@ -36,8 +36,9 @@ extern "C" {
 
 enum { CIMRGP_F32 = 0, CIMRGP_F64 = 1 };
 
-/* Outer block size of the factorisation (columns per panel).  Diagonal-block
- * inverses are kept in the workspace in slabs of CIMRGP_NB x CIMRGP_NB. */
+/* Outer block size of the factorisation (columns per panel).  The workspace
+ * keeps ceil(n/64) inverted 64x64 diagonal blocks followed by ceil(n/256)
+ * blocks (L_pp^-1)^T of CIMRGP_NB x CIMRGP_NB. */
 #define CIMRGP_NB 256
 
 int         cimrgp_version(void);
@@ -63,10 +64,11 @@ int cimrgp_rbf_cross(int dtype, const void* xa_dev, int64_t na,
 
 /* ---- D2: blocked in-place Cholesky  K = L L^T (lower) ----------------------
  * Replaces the Cholesky inside GPy's exact-Gaussian inference
- * (RegressionInput.py:61-63).  Right-looking, panel width CIMRGP_NB:
- * diagonal-block factor + inverse (one workgroup, MFMA inside), panel solve
- * as a product with the inverted diagonal block (MFMA), trailing SYRK/GEMM
- * update (MFMA 16x16x4 f64 / f32).
+ * (RegressionInput.py:61-63).  Right-looking over panels of CIMRGP_NB columns,
+ * left-looking over four 64-column sub-blocks inside a panel: diagonal-block
+ * factor + inverse (one workgroup), panel solve as a product with the
+ * inverted diagonal block (MFMA), trailing SYRK update (MFMA 16x16x4 f64 /
+ * f32) with one-panel look-ahead on an internal second stream.
  * workspace: cimrgp_potrf_workspace_bytes(dtype, n) bytes, keeps the inverted
  * diagonal blocks needed by cimrgp_potrs / cimrgp_trsm_rows afterwards.
  * info_dev: one int32, written asynchronously. */
