@@ -249,6 +249,8 @@ void k_diag64(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow, 
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = tid & 63;
     const int g = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave id: provably uniform
+    // latency-bound chain running next to MFMA-bound update workgroups: win issue arbitration
+    __builtin_amdgcn_s_setprio(3);
 
     STAMP(0);
     for (int e = tid; e < SB * SB; e += 256) {
@@ -371,6 +373,7 @@ static __device__ __forceinline__ void trsm64_body(T* __restrict__ Prow, int64_t
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rt = wave & 1, ch = wave >> 1;
+    __builtin_amdgcn_s_setprio(3);               // panel chain: ahead of co-resident update waves
     const T* Pprev = Prow - kprev;               // the panel's earlier columns of the same rows
 
     STAMP(8);
@@ -442,6 +445,23 @@ void k_trsm64(T* __restrict__ P1, int64_t ld1, int M1, int nb1,
     trsm64_body<T>(P + (int64_t)row0 * ldp, ldp, min(TR, M - row0), kw, kprev, Lrow, ldl, invL);
 }
 
+// All four sub-steps of a panel for rows that take no part in the factorisation itself (the
+// right-hand-side rows of a row-wise solve): one launch per panel instead of four.  A row
+// block only ever reads its own earlier results, written by this same workgroup.
+template <typename T>
+__global__ __launch_bounds__(256)
+void k_trsm256(T* __restrict__ P, int64_t ldp, int M, int w, const T* __restrict__ Lpanel, int64_t ldl,
+               const T* __restrict__ inv64)
+{
+    const int row0 = (int)blockIdx.x * TR;
+    const int mrows = min(TR, M - row0);
+    for (int c0 = 0; c0 < w; c0 += SB) {
+        if (c0) __syncthreads();                 // this workgroup's stores of the previous sub-step are visible
+        trsm64_body<T>(P + (int64_t)row0 * ldp + c0, ldp, mrows, min(SB, w - c0), c0,
+                       Lpanel + (int64_t)c0 * ldl, ldl, inv64 + (int64_t)(c0 / SB) * (SB * SB));
+    }
+}
+
 // ---------------------------------------------------------------------------
 // 256x256 inverses of the diagonal blocks, for the skinny solves: the identity is
 // carried through the panel solve, batched over ALL panels (blockIdx.y), one launch
@@ -484,7 +504,13 @@ static int panel_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info,
     for (int64_t k0 = 0; k0 < n; k0 += CIMRGP_NB) {
         const int64_t w = (n - k0 < CIMRGP_NB) ? (n - k0) : CIMRGP_NB;
         const int64_t k1 = k0 + w;
-        for (int64_t c0 = k0; c0 < k1; c0 += SB) {
+        if (!FACTOR && rows) {
+            hipLaunchKernelGGL((k_trsm256<T>), dim3((unsigned)((m + TR - 1) / TR)), dim3(256), 0, st,
+                               b + k0, ldb, (int)m, (int)w, (const T*)(kmat + k0 * ld + k0), ld,
+                               (const T*)(ws + (k0 / SB) * (SB * SB)));
+            CIMRGP_LAUNCH_CHECK(fn);
+        }
+        for (int64_t c0 = k0; FACTOR && c0 < k1; c0 += SB) {
             const int sw = (int)((k1 - c0 < SB) ? (k1 - c0) : SB);
             const int kprev = (int)(c0 - k0);
             const int64_t pc = c0 + sw;            // first row after this sub-block

@@ -14,7 +14,9 @@ namespace cimrgp {
 
 namespace {
 
+#ifndef CIMRGP_STAMP
 constexpr int SB   = 64;
+#endif
 constexpr int MAXQ = 8;
 constexpr int LSI  = SB + 1;
 
@@ -40,68 +42,79 @@ constexpr int ST = 1024;           // threads per workgroup of the skinny solves
 // workgroup 0 publishes it, then each workgroup updates 64 rows below the panel
 // (16 lanes per row, 16 contiguous elements per lane).
 // ---------------------------------------------------------------------------
-template <typename T>
+// Q = number of right-hand sides at compile time: a run-time `if (c < q)` inside the load loops
+// is a branch per iteration and serialises the loads (one memory round trip each).
+template <typename T, int Q>
 __global__ __launch_bounds__(ST)
 void k_fwd_panel(const T* __restrict__ L, int64_t ld, int n, const T* __restrict__ invT,
                  T* __restrict__ work, T* __restrict__ out, int q, int k0, int w)
 {
-    __shared__ T ws_[MAXQ][PW];         // right-hand side of the panel
-    __shared__ T zs[MAXQ][PW];          // solution of the panel
-    __shared__ T red[4][MAXQ][PW];
+    __shared__ T ws_[Q][PW];         // right-hand side of the panel
+    __shared__ T zs[Q][PW];          // solution of the panel
+    __shared__ T red[4][Q][PW];
     const int tid = threadIdx.x;
-    for (int e = tid; e < q * PW; e += ST) {
+    STAMP(20);
+    for (int e = tid; e < Q * PW; e += ST) {
         const int c = e / PW, u = e - c * PW;
         ws_[c][u] = (u < w) ? work[(int64_t)c * n + k0 + u] : (T)0;
     }
     __syncthreads();
+    STAMP(21);
     {
         const int col = tid & (PW - 1), part = tid >> 8;          // 4 row parts of 64
         const T* bp = invT + (int64_t)(k0 / PW) * (PW * PW) + col;
-        T acc[MAXQ];
+        T acc[Q];
 #pragma unroll
-        for (int c = 0; c < MAXQ; ++c) acc[c] = (T)0;
+        for (int c = 0; c < Q; ++c) acc[c] = (T)0;
         const int rbeg = part * 64;
         if (rbeg <= col) {                                        // invT is upper triangular: rows <= col
 #pragma unroll 16
             for (int r = rbeg; r < rbeg + 64; ++r) {
                 const T bv = bp[(int64_t)r * PW];
 #pragma unroll
-                for (int c = 0; c < MAXQ; ++c)
-                    if (c < q) acc[c] += bv * ws_[c][r];
+                for (int c = 0; c < Q; ++c)
+                    acc[c] += bv * ws_[c][r];
             }
         }
 #pragma unroll
-        for (int c = 0; c < MAXQ; ++c)
-            if (c < q) red[part][c][col] = acc[c];
+        for (int c = 0; c < Q; ++c)
+            red[part][c][col] = acc[c];
     }
     __syncthreads();
-    for (int e = tid; e < q * PW; e += ST) {
+    STAMP(22);
+    for (int e = tid; e < Q * PW; e += ST) {
         const int c = e / PW, u = e - c * PW;
         const T v = red[0][c][u] + red[1][c][u] + red[2][c][u] + red[3][c][u];
         zs[c][u] = v;
         if (blockIdx.x == 0 && u < w) out[(int64_t)c * n + k0 + u] = v;
     }
     __syncthreads();
+    STAMP(23);
     // 64 rows below the panel per workgroup
     const int l16 = tid & 15, slot = tid >> 4;
     const int r = k0 + w + blockIdx.x * 64 + slot;
     if (r < n) {
         const T* lp = L + (int64_t)r * ld + k0 + l16 * 16;
-        T sum[MAXQ];
+        T sum[Q];
 #pragma unroll
-        for (int c = 0; c < MAXQ; ++c) sum[c] = (T)0;
+        for (int c = 0; c < Q; ++c) sum[c] = (T)0;
         T lv[16];
+        if (w == PW) {                                 // full panel: unconditional, independent loads
 #pragma unroll
-        for (int e = 0; e < 16; ++e) lv[e] = (l16 * 16 + e < w) ? lp[e] : (T)0;
+            for (int e = 0; e < 16; ++e) lv[e] = lp[e];
+        } else {
 #pragma unroll
-        for (int c = 0; c < MAXQ; ++c)
-            if (c < q) {
+            for (int e = 0; e < 16; ++e) lv[e] = (l16 * 16 + e < w) ? lp[e] : (T)0;
+        }
+#pragma unroll
+        for (int c = 0; c < Q; ++c)
+            {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) sum[c] += lv[e] * zs[c][l16 * 16 + e];
             }
 #pragma unroll
-        for (int c = 0; c < MAXQ; ++c) {
-            if (c < q) {
+        for (int c = 0; c < Q; ++c) {
+            {
                 T sv = sum[c];
                 sv += __shfl_xor(sv, 8, 16);
                 sv += __shfl_xor(sv, 4, 16);
@@ -111,6 +124,7 @@ void k_fwd_panel(const T* __restrict__ L, int64_t ld, int n, const T* __restrict
             }
         }
     }
+    STAMP(24);
 }
 
 // ---------------------------------------------------------------------------
@@ -118,16 +132,16 @@ void k_fwd_panel(const T* __restrict__ L, int64_t ld, int n, const T* __restrict
 // w[cols left of the panel] -= L[panel, cols]^T a_p   (thread = column, 16-way split over
 // the panel's rows, 64 columns per workgroup).
 // ---------------------------------------------------------------------------
-template <typename T>
+template <typename T, int Q>
 __global__ __launch_bounds__(ST)
 void k_bwd_panel(const T* __restrict__ L, int64_t ld, int n, const T* __restrict__ invT,
                  T* __restrict__ work, T* __restrict__ out, int q, int k0, int w)
 {
-    __shared__ T ws_[MAXQ][PW];
-    __shared__ T zs[MAXQ][PW];
-    __shared__ T red[16][MAXQ][SB];
+    __shared__ T ws_[Q][PW];
+    __shared__ T zs[Q][PW];
+    __shared__ T red[16][Q][SB];
     const int tid = threadIdx.x;
-    for (int e = tid; e < q * PW; e += ST) {
+    for (int e = tid; e < Q * PW; e += ST) {
         const int c = e / PW, u = e - c * PW;
         ws_[c][u] = (u < w) ? work[(int64_t)c * n + k0 + u] : (T)0;
     }
@@ -142,18 +156,18 @@ void k_bwd_panel(const T* __restrict__ L, int64_t ld, int n, const T* __restrict
             T bv[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) bv[e] = rp[e];
-            T sum[MAXQ];
+            T sum[Q];
 #pragma unroll
-            for (int c = 0; c < MAXQ; ++c) sum[c] = (T)0;
+            for (int c = 0; c < Q; ++c) sum[c] = (T)0;
 #pragma unroll
-            for (int c = 0; c < MAXQ; ++c)
-                if (c < q) {
+            for (int c = 0; c < Q; ++c)
+                {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) sum[c] += bv[e] * ws_[c][l16 * 16 + e];
                 }
 #pragma unroll
-            for (int c = 0; c < MAXQ; ++c) {
-                if (c < q) {
+            for (int c = 0; c < Q; ++c) {
+                {
                     T sv = sum[c];
                     sv += __shfl_xor(sv, 8, 16);
                     sv += __shfl_xor(sv, 4, 16);
@@ -170,29 +184,35 @@ void k_bwd_panel(const T* __restrict__ L, int64_t ld, int n, const T* __restrict
     __syncthreads();
     const int t = tid & 63, part = tid >> 6;                      // 16 row parts of 16
     const int col = blockIdx.x * SB + t;
-    T acc[MAXQ];
+    T acc[Q];
 #pragma unroll
-    for (int c = 0; c < MAXQ; ++c) acc[c] = (T)0;
+    for (int c = 0; c < Q; ++c) acc[c] = (T)0;
     if (col < k0) {
         const T* lp = L + (int64_t)k0 * ld + col;
         const int ubeg = part * 16;
+        T lv[16];
+        if (w == PW) {                                 // full panel: unconditional, independent loads
+#pragma unroll
+            for (int e = 0; e < 16; ++e) lv[e] = lp[(int64_t)(ubeg + e) * ld];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) lv[e] = (ubeg + e < w) ? lp[(int64_t)(ubeg + e) * ld] : (T)0;
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int u = ubeg + e;
-            const T lv = (u < w) ? lp[(int64_t)u * ld] : (T)0;
 #pragma unroll
-            for (int c = 0; c < MAXQ; ++c)
-                if (c < q) acc[c] += lv * zs[c][u];
+            for (int c = 0; c < Q; ++c)
+                acc[c] += lv[e] * zs[c][ubeg + e];
         }
     }
 #pragma unroll
-    for (int c = 0; c < MAXQ; ++c)
-        if (c < q) red[part][c][t] = acc[c];
+    for (int c = 0; c < Q; ++c)
+        red[part][c][t] = acc[c];
     __syncthreads();
     if (part == 0 && col < k0) {
 #pragma unroll
-        for (int c = 0; c < MAXQ; ++c) {
-            if (c < q) {
+        for (int c = 0; c < Q; ++c) {
+            {
                 T sv = (T)0;
 #pragma unroll
                 for (int pp = 0; pp < 16; ++pp) sv += red[pp][c][t];
@@ -203,7 +223,7 @@ void k_bwd_panel(const T* __restrict__ L, int64_t ld, int n, const T* __restrict
 }
 
 // D5 tail: one wave per row of W.
-template <typename T>
+template <typename T, int Q>
 __global__ __launch_bounds__(256)
 void k_predict_from_w(const T* __restrict__ W, int ns, int n, int64_t ldw, const T* __restrict__ z, int q,
                       T sf2_plus, const T* __restrict__ bias, T* __restrict__ mean, T* __restrict__ var,
@@ -214,32 +234,32 @@ void k_predict_from_w(const T* __restrict__ W, int ns, int n, int64_t ldw, const
     if (row >= ns) return;
     const T* wp = W + (int64_t)row * ldw;
     T ss = (T)0;
-    T sm[MAXQ];
+    T sm[Q];
 #pragma unroll
-    for (int c = 0; c < MAXQ; ++c) sm[c] = (T)0;
+    for (int c = 0; c < Q; ++c) sm[c] = (T)0;
     const bool want_mean = (mean != nullptr) && (z != nullptr);
     for (int j = lane; j < n; j += 64) {
         const T w = wp[j];
         ss += w * w;
         if (want_mean) {
 #pragma unroll
-            for (int c = 0; c < MAXQ; ++c)
-                if (c < q) sm[c] += w * z[(int64_t)j * q + c];
+            for (int c = 0; c < Q; ++c)
+                sm[c] += w * z[(int64_t)j * q + c];
         }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         ss += __shfl_xor(ss, off, 64);
 #pragma unroll
-        for (int c = 0; c < MAXQ; ++c)
-            if (c < q) sm[c] += __shfl_xor(sm[c], off, 64);
+        for (int c = 0; c < Q; ++c)
+            sm[c] += __shfl_xor(sm[c], off, 64);
     }
     if (lane == 0) {
         if (var) { const T v = sf2_plus - ss; var[row] = accumulate ? var[row] + v : v; }
         if (want_mean) {
 #pragma unroll
-            for (int c = 0; c < MAXQ; ++c) {
-                if (c < q) {
+            for (int c = 0; c < Q; ++c) {
+                {
                     const T m = sm[c] + (bias ? bias[c] : (T)0);
                     T* o = mean + (int64_t)row * q + c;
                     *o = accumulate ? *o + m : m;
@@ -250,6 +270,19 @@ void k_predict_from_w(const T* __restrict__ W, int ns, int n, int64_t ldw, const
 }
 
 }  // namespace
+
+// Dispatch the run-time number of right-hand sides to a compile-time constant QQ.
+#define CIMRGP_Q_SWITCH(q_, ...)                                   \
+    switch (q_) {                                                  \
+        case 1: { constexpr int QQ = 1; __VA_ARGS__; } break;      \
+        case 2: { constexpr int QQ = 2; __VA_ARGS__; } break;      \
+        case 3: { constexpr int QQ = 3; __VA_ARGS__; } break;      \
+        case 4: { constexpr int QQ = 4; __VA_ARGS__; } break;      \
+        case 5: { constexpr int QQ = 5; __VA_ARGS__; } break;      \
+        case 6: { constexpr int QQ = 6; __VA_ARGS__; } break;      \
+        case 7: { constexpr int QQ = 7; __VA_ARGS__; } break;      \
+        default: { constexpr int QQ = 8; __VA_ARGS__; } break;     \
+    }
 
 template <typename T>
 int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* z_out, T* scratch, hipStream_t st)
@@ -268,8 +301,8 @@ int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* 
         const int w = (int)((n - k0 < PW) ? (n - k0) : PW);
         const int64_t below = n - (k0 + w);
         const unsigned grid = (unsigned)((below + 63) / 64);
-        hipLaunchKernelGGL((k_fwd_panel<T>), dim3(grid ? grid : 1), dim3(ST), 0, st, l, ld, (int)n,
-                           invT, work, res, q, (int)k0, w);
+        CIMRGP_Q_SWITCH(q, hipLaunchKernelGGL((k_fwd_panel<T, QQ>), dim3(grid ? grid : 1), dim3(ST), 0, st, l, ld, (int)n,
+                                              invT, work, res, q, (int)k0, w));
         CIMRGP_LAUNCH_CHECK(fn);
     }
     if (z_out) {
@@ -282,8 +315,8 @@ int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* 
     for (int64_t k0 = last; k0 >= 0; k0 -= PW) {
         const int w = (int)((n - k0 < PW) ? (n - k0) : PW);
         const unsigned grid = (unsigned)((k0 + SB - 1) / SB);
-        hipLaunchKernelGGL((k_bwd_panel<T>), dim3(grid ? grid : 1), dim3(ST), 0, st, l, ld, (int)n,
-                           invT, work, res, q, (int)k0, w);
+        CIMRGP_Q_SWITCH(q, hipLaunchKernelGGL((k_bwd_panel<T, QQ>), dim3(grid ? grid : 1), dim3(ST), 0, st, l, ld, (int)n,
+                                              invT, work, res, q, (int)k0, w));
         CIMRGP_LAUNCH_CHECK(fn);
     }
     hipLaunchKernelGGL((k_transpose_nq<T>), dim3(tg), dim3(256), 0, st, (const T*)res, rhs, n, q, 0);
@@ -299,8 +332,8 @@ int predict_from_w_run(const T* w, int64_t ns, int64_t n, int64_t ldw, const T* 
     if (ns <= 0) return 0;
     CIMRGP_REQUIRE(q >= 0 && q <= MAXQ, fn, "number of outputs must be <= 8");
     CIMRGP_REQUIRE(ns < (1ll << 31) && n < (1ll << 31), fn, "too many points");
-    hipLaunchKernelGGL((k_predict_from_w<T>), dim3((unsigned)((ns + 3) / 4)), dim3(256), 0, st,
-                       w, (int)ns, (int)n, ldw, z, q, (T)(sf2 + extra), bias, mean, var, accumulate);
+    CIMRGP_Q_SWITCH(q > 0 ? q : 1, hipLaunchKernelGGL((k_predict_from_w<T, QQ>), dim3((unsigned)((ns + 3) / 4)), dim3(256), 0, st,
+                                                      w, (int)ns, (int)n, ldw, z, q, (T)(sf2 + extra), bias, mean, var, accumulate));
     CIMRGP_LAUNCH_CHECK(fn);
     return 0;
 }

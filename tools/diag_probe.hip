@@ -2,6 +2,7 @@
 #define CIMRGP_STAMP 1
 #include "../cimrgp_amd/csrc/potrf.hip"
 #include "../cimrgp_amd/csrc/gemm_nt.hip"
+#include "../cimrgp_amd/csrc/solve.hip"
 #include "../cimrgp_amd/csrc/api.hip"
 #include <vector>
 #include <cmath>
@@ -9,8 +10,6 @@ using namespace cimrgp;
 namespace cimrgp {
 template <typename T> int rbf_gram_run(const T*, int64_t, const T*, int64_t, int, double, double, double, T*, int64_t, bool, bool, hipStream_t) { return 0; }
 template <typename T> int predict_mean_run(const T*, int64_t, int, const T*, int, const T*, int64_t, double, double, const T*, T*, int, hipStream_t) { return 0; }
-template <typename T> int potrs_run(const T*, int64_t, int64_t, const T*, T*, int, T*, T*, hipStream_t) { return 0; }
-template <typename T> int predict_from_w_run(const T*, int64_t, int64_t, int64_t, const T*, int, double, double, const T*, T*, T*, int, hipStream_t) { return 0; }
 template <typename T> int misc_block_stats(const T*, const T*, int64_t, int, T*, hipStream_t) { return 0; }
 template <typename T> int misc_residual(const T*, const T*, const T*, int64_t, int, T*, hipStream_t) { return 0; }
 template <typename T> int misc_train_mean(const T*, const T*, const T*, const T*, int64_t, int, T*, int, hipStream_t) { return 0; }
@@ -41,6 +40,23 @@ int main()
             hipDeviceSynchronize();
             hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamp), sizeof(st));
             if (rep) printf("trsm64 kprev=%3d: kloop %lld  stage %lld  mma %lld  store %lld  total %lld ticks (%.1f us)\n", kprev, st[9]-st[8], st[10]-st[9], st[11]-st[10], st[12]-st[11], st[12]-st[8], (st[12]-st[8])/2350.0);
+        }
+    }
+    {   // skinny forward panel step on an 8192 matrix (values irrelevant)
+        const int nn = 8192; const int64_t l2 = 8192;
+        double *dL, *dws2, *dwork, *dout;
+        hipMalloc(&dL, (size_t)nn * l2 * 8); hipMemset(dL, 0, (size_t)nn * l2 * 8);
+        hipMalloc(&dws2, (size_t)(128 * 4096 + 32 * 65536) * 8); hipMemset(dws2, 0, (size_t)(128 * 4096 + 32 * 65536) * 8);
+        hipMalloc(&dwork, 2 * nn * 8); hipMalloc(&dout, 2 * nn * 8); hipMemset(dwork, 0, 2 * nn * 8);
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            hipEventRecord(e0);
+            hipLaunchKernelGGL((k_fwd_panel<double, 2>), dim3(124), dim3(1024), 0, 0, dL, l2, nn, dws2 + 128 * 4096, dwork, dout, 2, 0, 256);
+            hipEventRecord(e1); hipDeviceSynchronize();
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamp), sizeof(st));
+            printf("fwd_panel: load %lld  invapply %lld  reduce %lld  update %lld  total %lld ticks (%.1f us); kernel %.1f us\n",
+                   st[21]-st[20], st[22]-st[21], st[23]-st[22], st[24]-st[23], st[24]-st[20], (st[24]-st[20])/2350.0, ms*1e3);
         }
     }
     // trailing-update kernel: one workgroup alone, then a full grid
