@@ -185,6 +185,18 @@ static __device__ __forceinline__ void mma_chunk32(typename Mx<T>::acc_t (&acc)[
     }
 }
 
+// Wave-local broadcast of lane `src`'s value (src wave-uniform): v_readlane, no LDS.
+static __device__ __forceinline__ double bcast_lane(double v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+static __device__ __forceinline__ float bcast_lane(float v, int src)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
 template <typename T> static __device__ __forceinline__ T rsqrt_refined(T d);
 template <> __device__ __forceinline__ double rsqrt_refined<double>(double d)
 {
@@ -245,7 +257,7 @@ void k_diag64(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow, 
     constexpr int LS = SB + 1;
     __shared__ __attribute__((aligned(16))) unsigned char chunk[TL::BYTES];   // Lrow chunk, later L^-1 out
     __shared__ T S[SB * LS];                                                  // Schur block, later L out
-    __shared__ __attribute__((aligned(16))) T comb[2][SB];                    // column j of A
+    __shared__ __attribute__((aligned(16))) T comb4[2][SB][4];                // four pivot-time columns of A
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = tid & 63;
     const int g = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave id: provably uniform
@@ -289,46 +301,67 @@ void k_diag64(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow, 
     for (int e = tid; e < SB * SB; e += 256) iout[e] = (T)0;
     STAMP(2);
 
-    // Column j+1 is published as soon as its own entries have been updated at pivot j -- before
-    // the other 15 register slots -- so the LDS store/barrier latency of the next pivot overlaps
-    // the rest of this pivot's update (software pipelining of the publish).
-    if (g == 0) comb[0][i] = a[0];                   // column 0
+    // Column loop, FOUR pivots per barrier.  The wave that owns columns j0..j0+3 (same register
+    // slots u0..u0+3 of every lane) eliminates them among themselves with wave-local broadcasts
+    // (v_readlane, no LDS, no barrier), publishes the four pivot-time columns with two 16-byte
+    // LDS stores per lane, and after ONE barrier every wave applies the rank-4 update to its
+    // slots right of the block.  A lane that is itself a pivot row of the block (i = j0 + p)
+    // starts its not-yet-born inverse entries from 0 and takes contributions from pivots >= p only.
     for (int gg = 0; gg < 4; ++gg) {
 #pragma unroll
-        for (int u0 = 0; u0 < 16; ++u0) {
-            const int j = 16 * gg + u0;
-            if (j < w) {                             // uniform
-                const T* cb = comb[j & 1];
-                T* cbn = comb[(j + 1) & 1];
-                lds_barrier();
-                if (g >= gg) {
-                    const T d  = cb[j];
-                    const T ci = cb[i];
-                    const T r  = rsqrt_refined<T>(d);
-                    const T h  = (i == j) ? r : ci * r;
-                    const T nhr = -h * r;            // A[i][k] -= A[k][j] * (h r)
-                    const bool pivot_row = (i == j);
-                    if (g > gg) {
-                        // slot 0 first: if this wave owns column j+1 (u0 == 15, g == gg + 1) it is the next pivot
-                        a[0] = fma(nhr, cb[16 * g], pivot_row ? (T)0 : a[0]);
-                        if (u0 == 15 && g == gg + 1) cbn[i] = a[0];
+        for (int ub = 0; ub < 4; ++ub) {
+            constexpr int BC = 4;
+            const int u0 = BC * ub;
+            const int j0 = 16 * gg + u0;
+            T (*cb)[BC] = comb4[(j0 >> 2) & 1];
+            T colv[BC], rr[BC];
+            if (g == gg) {
 #pragma unroll
-                        for (int u = 1; u < 16; ++u)
-                            a[u] = fma(nhr, cb[16 * g + u], pivot_row ? (T)0 : a[u]);
-                    } else {
-                        if (u0 < 15) {               // next pivot column lives in this wave, slot u0 + 1
-                            a[u0 + 1] = fma(nhr, cb[16 * g + u0 + 1], pivot_row ? (T)0 : a[u0 + 1]);
-                            cbn[i] = a[u0 + 1];
-                        }
+                for (int t = 0; t < BC; ++t) {
+                    const int j = j0 + t;
+                    colv[t] = a[u0 + t];
+                    const T d = bcast_lane(colv[t], j);
+                    const T r = rsqrt_refined<T>(d);
+                    rr[t] = r;
+                    const T h = (i == j) ? r : colv[t] * r;
+                    const T nhr = -h * r;
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) {
-                            if (u > u0 + 1)
-                                a[u] = fma(nhr, cb[16 * g + u], pivot_row ? (T)0 : a[u]);
-                        }
-                        if (!(d > (T)0) && i == j) atomicCAS(info, 0, col_base + j + 1);
-                        if (i >= j) lout[i * LS + j] = (i == j) ? d * r : h;
-                        else        iout[j * SB + i] = h;
-                        if (i == j) iout[j * SB + j] = r;
+                    for (int t2 = t + 1; t2 < BC; ++t2) {
+                        const T ak = bcast_lane(colv[t], j0 + t2);          // A[k][j] at pivot time
+                        a[u0 + t2] = fma(nhr, ak, (i == j) ? (T)0 : a[u0 + t2]);
+                    }
+                    if (!(d > (T)0) && i == j && j < w) atomicCAS(info, 0, col_base + j + 1);
+                    if (i >= j) lout[i * LS + j] = (i == j) ? d * r : h;
+                    else        iout[j * SB + i] = h;
+                    if (i == j) iout[j * SB + j] = r;
+                }
+#pragma unroll
+                for (int t = 0; t < BC; ++t) cb[i][t] = colv[t];
+            }
+            lds_barrier();
+            if (g >= gg) {
+                if (g != gg) {
+#pragma unroll
+                    for (int t = 0; t < BC; ++t) {
+                        colv[t] = cb[i][t];
+                        rr[t] = rsqrt_refined<T>(cb[j0 + t][t]);
+                    }
+                }
+                const bool in_block = (i >= j0) && (i < j0 + BC);
+                T nhr[BC];
+#pragma unroll
+                for (int t = 0; t < BC; ++t) {
+                    const T h = (i == j0 + t) ? rr[t] : colv[t] * rr[t];
+                    nhr[t] = (in_block && i > j0 + t) ? (T)0 : -h * rr[t];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    if (g > gg || u >= u0 + BC) {               // columns right of the block
+                        const int k = 16 * g + u;
+                        T v = in_block ? (T)0 : a[u];
+#pragma unroll
+                        for (int t = 0; t < BC; ++t) v = fma(nhr[t], cb[k][t], v);
+                        a[u] = v;
                     }
                 }
             }
