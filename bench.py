@@ -189,6 +189,16 @@ def main():
                          "avg_launch_gflop": tr_fl.value / max(1, tr_cnt.value) / 1e9,
                          "traffic": None},
         }
+        # HBM traffic of that kernel comes from the committed rocprofv3 --pmc passes of this same
+        # command (counters cannot be collected from inside the process being timed)
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_trailing_update.json")
+        if args.dtype == "f64" and n == 8192 and os.path.exists(pmc):
+            with open(pmc) as fh:
+                pj = json.load(fh)
+            out["roofline"]["traffic"] = pj["traffic_bytes_per_launch"]
+            out["roofline"]["traffic_unit"] = "bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_trailing_update.json)"
+            mm = [n - 256 * (p + 2) for p in range((n // 256) - 2)]
+            out["roofline"]["algorithmic_bytes_per_launch"] = float(np.mean([m * (m + 1) / 2 * 8 * 2 + m * 256 * 8 for m in mm]))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, ns, q, ell, sf2, noise, 1234)
         print(json.dumps(out))

@@ -97,13 +97,14 @@ constexpr int PM_TS = 8;
 constexpr int PM_PH = 32;
 constexpr int MAXQ  = 8;
 
-template <typename T, int D>
+// Q = number of outputs at compile time (a run-time guard inside the loop serialises the loads).
+template <typename T, int D, int Q>
 __global__ __launch_bounds__(256)
 void k_predict_mean(const T* __restrict__ x, int n, int d, const T* __restrict__ alpha, int q,
                     const T* __restrict__ xs, int ns, T neg_half_inv_l2, T sf2,
                     const T* __restrict__ bias, T* __restrict__ mean, int accumulate)
 {
-    __shared__ T red[PM_PH][PM_TS][MAXQ];
+    __shared__ T red[PM_PH][PM_TS][Q];
     const int tid = threadIdx.x;
     const int t  = tid & (PM_TS - 1);
     const int ph = tid / PM_TS;
@@ -112,9 +113,9 @@ void k_predict_mean(const T* __restrict__ x, int n, int d, const T* __restrict__
     T xt[DD];
 #pragma unroll
     for (int k = 0; k < DD; ++k) xt[k] = ((D || k < d) && gi < ns) ? xs[(int64_t)gi * d + k] : (T)0;
-    T sum[MAXQ];
+    T sum[Q];
 #pragma unroll
-    for (int c = 0; c < MAXQ; ++c) sum[c] = (T)0;
+    for (int c = 0; c < Q; ++c) sum[c] = (T)0;
     for (int j = ph; j < n; j += PM_PH) {
         T d2 = (T)0;
 #pragma unroll
@@ -126,11 +127,10 @@ void k_predict_mean(const T* __restrict__ x, int n, int d, const T* __restrict__
         }
         const T kv = sf2 * exp(d2 * neg_half_inv_l2);
 #pragma unroll
-        for (int c = 0; c < MAXQ; ++c)
-            if (c < q) sum[c] += kv * alpha[(int64_t)j * q + c];
+        for (int c = 0; c < Q; ++c) sum[c] += kv * alpha[(int64_t)j * Q + c];
     }
 #pragma unroll
-    for (int c = 0; c < MAXQ; ++c) red[ph][t][c] = sum[c];
+    for (int c = 0; c < Q; ++c) red[ph][t][c] = sum[c];
     __syncthreads();
     if (tid < PM_TS * q) {
         const int tt = tid / q, c = tid - tt * q;
@@ -191,12 +191,24 @@ int predict_mean_run(const T* x, int64_t n, int d, const T* alpha, int q, const 
     CIMRGP_REQUIRE(ell > 0.0, fn, "length-scale must be positive");
     CIMRGP_REQUIRE(n < (1ll << 31) && ns < (1ll << 31), fn, "too many points");
     const unsigned grid = (unsigned)((ns + PM_TS - 1) / PM_TS);
-#define CIMRGP_PM_LAUNCH(D_)                                                              \
-    hipLaunchKernelGGL((k_predict_mean<T, D_>), dim3(grid), dim3(256), 0, st, x, (int)n, d, \
+#define CIMRGP_PM_LAUNCH(D_, Q_)                                                              \
+    hipLaunchKernelGGL((k_predict_mean<T, D_, Q_>), dim3(grid), dim3(256), 0, st, x, (int)n, d, \
                        alpha, q, xs, (int)ns, (T)(-0.5 / (ell * ell)), (T)sf2, bias, mean, accumulate)
-    if (d == 1)      CIMRGP_PM_LAUNCH(1);
-    else if (d == 2) CIMRGP_PM_LAUNCH(2);
-    else             CIMRGP_PM_LAUNCH(0);
+#define CIMRGP_PM_D(Q_)                                     \
+    { if (d == 1)      CIMRGP_PM_LAUNCH(1, Q_);             \
+      else if (d == 2) CIMRGP_PM_LAUNCH(2, Q_);             \
+      else             CIMRGP_PM_LAUNCH(0, Q_); }
+    switch (q) {
+        case 1: CIMRGP_PM_D(1); break;
+        case 2: CIMRGP_PM_D(2); break;
+        case 3: CIMRGP_PM_D(3); break;
+        case 4: CIMRGP_PM_D(4); break;
+        case 5: CIMRGP_PM_D(5); break;
+        case 6: CIMRGP_PM_D(6); break;
+        case 7: CIMRGP_PM_D(7); break;
+        default: CIMRGP_PM_D(8); break;
+    }
+#undef CIMRGP_PM_D
 #undef CIMRGP_PM_LAUNCH
     CIMRGP_LAUNCH_CHECK(fn);
     return 0;

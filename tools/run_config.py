@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Run one of BASELINE.json's configurations end to end through the host API on one GPU
+and print a JSON line (timings, posteriors/s, sanity checks).  Diagnostic / reporting tool;
+bench.py is the contract benchmark.
+
+    python tools/run_config.py --config 3            # N=65536, 5 layers (31 blocks)
+    python tools/run_config.py --config 3 --n 16384  # scaled down
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=3)
+    ap.add_argument("--n", type=int, default=None)
+    ap.add_argument("--dtype", default="f64")
+    ap.add_argument("--check", action="store_true", help="compare with the CPU oracle (small n only)")
+    args = ap.parse_args()
+    import torch
+    import cimrgp_amd as ca
+
+    rng = np.random.default_rng(1234)
+    if args.config == 3:
+        n = args.n or 65536
+        res, d = 4, 1
+        x = np.sort(rng.uniform(-np.sqrt(3), np.sqrt(3), size=(n, 1)), axis=0)
+    elif args.config == 4:      # 2-D, hierarchy started where blocks fit one GPU
+        n = args.n or 131072
+        res, d = 4, 2
+        x = rng.uniform(-np.sqrt(3), np.sqrt(3), size=(n, 2))
+        x = x[np.lexsort((x[:, 1], np.floor(x[:, 0] * 8)))]      # strips: contiguous index blocks are compact
+    else:
+        raise SystemExit("config must be 3 or 4")
+    q = 2
+    y = np.hstack([np.sin(3 * x[:, :1] + k) + 0.5 * np.sin(17 * x[:, :1] ** 2) for k in range(q)])
+    y += 0.1 * rng.normal(size=y.shape)
+    ns = n // 4
+    xs = np.sort(rng.uniform(-1.7, 1.7, size=(ns, d)), axis=0) if d == 1 else rng.uniform(-1.7, 1.7, size=(ns, d))
+    if d == 2:
+        xs = xs[np.lexsort((xs[:, 1], np.floor(xs[:, 0] * 8)))]
+    kernels = [ca.RBFKernel(l=1.0 / 2 ** j, sf=1.0, noise=0.01) for j in range(res + 1)]
+    idx = ca.IndexSetUniform(n, res, 2)
+    idx_t = ca.IndexSetUniform(ns, res, 2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    model = ca.MultiResolutionGaussianProcess([x, y], index_set_obj=idx, spectral_density_obj=kernels,
+                                              dtype=args.dtype, keep_factors=True)
+    model.fit()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    mean, var = model.get_predicted_mean_and_var(xs, idx_t)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    nblocks = sum(model.n_regions)
+    out = dict(config=args.config, n=n, layers=res + 1, blocks=nblocks, dtype=args.dtype,
+               fit_s=t1 - t0, predict_s=t2 - t1, posteriors_per_s=nblocks / (t2 - t0),
+               cholesky_flops=float(sum(sum(float(m) ** 3 / 3 for m in layer) for layer in model.n_samps)),
+               mean_finite=bool(np.isfinite(mean).all()), var_finite=bool(np.isfinite(var).all()),
+               var_min=float(var.min()), var_max=float(var.max()),
+               train_rmse=float(np.sqrt(np.mean((model._f_bar_final.cpu().numpy() - y) ** 2))),
+               peak_mem_GiB=torch.cuda.max_memory_allocated() / 2 ** 30)
+    if args.check:
+        import oracle
+        xn, _, mu, sd = oracle.normalize_inputs(x)
+        specs = [oracle.DenseLayerSpec(1.0 / 2 ** j, 1.0, 0.01) for j in range(res + 1)]
+        om, _ = oracle.mrgp_fit(xn, y, oracle.index_bounds_uniform(n, res, 2), specs)
+        omean, ovar = oracle.mrgp_predict(xn, om, specs, (xs - mu) / sd, oracle.index_bounds_uniform(ns, res, 2))
+        out["rel_err_mean"] = float(np.max(np.abs(mean - omean)) / np.max(np.abs(omean)))
+        out["rel_err_var"] = float(np.max(np.abs(var - ovar)) / np.max(np.abs(ovar)))
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
