@@ -51,9 +51,13 @@ class DenseBlock(object):
         self.r = dev.residual(y, f_bar, self.bias)
         self.lbuf = dev.rbf_gram(self.x, k.l, k.sf, 0.0, lower_only=True)
         dev.add_diag(self.lbuf, self.n, self.noise)
-        self.ws, self.info = dev.potrf(self.lbuf, self.n)
-        self.alpha = self.r.clone()
-        self.z = dev.potrs(self.lbuf, self.n, self.ws, self.alpha, want_z=True)
+        # the targets ride through the factorisation as q extra rows: z = L^-1 r comes out of the
+        # same panel sweep (no separate forward solve), then one backward solve gives alpha
+        q_rows = dev.alloc_matrix(q, self.n, y.dtype, y.device)
+        q_rows[:q, :self.n] = self.r.t()
+        self.ws, self.info = dev.potrf_rows(self.lbuf, self.n, q_rows, q)
+        self.z = q_rows[:q, :self.n].t().contiguous()
+        self.alpha = dev.solve_lt(self.lbuf, self.n, self.ws, self.z.clone())
         # K_noiseless alpha = r - noise * alpha: no second pass over the Gram matrix
         dev.train_mean(self.r, self.alpha, self.bias, self.noise, train_out, accumulate=True)
         if not keep_factor:

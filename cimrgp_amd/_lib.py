@@ -23,6 +23,8 @@ SIGNATURES = {
     "cimrgp_rbf_cross": (_i32, [_i32, _vp, _i64, _vp, _i64, _i32, _dbl, _dbl, _vp, _i64, _vp]),
     "cimrgp_potrf_workspace_bytes": (_sz, [_i32, _i64]),
     "cimrgp_potrf": (_i32, [_i32, _vp, _i64, _i64, _vp, _sz, _vp, _vp]),
+    "cimrgp_potrf_rows": (_i32, [_i32, _vp, _i64, _i64, _vp, _sz, _vp, _vp, _i64, _i64, _vp]),
+    "cimrgp_solve_lt": (_i32, [_i32, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _vp]),
     "cimrgp_potrs": (_i32, [_i32, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _vp]),
     "cimrgp_trsm_rows": (_i32, [_i32, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp]),
     "cimrgp_predict_mean": (_i32, [_i32, _vp, _i64, _i32, _vp, _i32, _vp, _i64, _dbl, _dbl, _vp, _vp, _i32, _vp]),

@@ -95,8 +95,24 @@ int cimrgp_potrf(int dtype, void* k_dev, int64_t n, int64_t ldk, void* workspace
     CIMRGP_REQUIRE(workspace_bytes >= cimrgp_potrf_workspace_bytes(dtype, n), fn, "workspace too small");
     if (n == 0) return check_hip(hipMemsetAsync(info_dev, 0, sizeof(int32_t), S(stream)), fn, "memset");
     DISPATCH(dtype, fn,
-             potrf_run<float>((float*)k_dev, n, ldk, (float*)workspace_dev, info_dev, S(stream)),
-             potrf_run<double>((double*)k_dev, n, ldk, (double*)workspace_dev, info_dev, S(stream)));
+             potrf_run<float>((float*)k_dev, n, ldk, (float*)workspace_dev, info_dev, nullptr, 0, 0, S(stream)),
+             potrf_run<double>((double*)k_dev, n, ldk, (double*)workspace_dev, info_dev, nullptr, 0, 0, S(stream)));
+}
+
+int cimrgp_potrf_rows(int dtype, void* k_dev, int64_t n, int64_t ldk, void* workspace_dev, size_t workspace_bytes,
+                      int32_t* info_dev, void* b_dev, int64_t m, int64_t ldb, void* stream)
+{
+    const char* fn = "cimrgp_potrf_rows";
+    CIMRGP_REQUIRE(k_dev && workspace_dev && info_dev && b_dev, fn, "null pointer");
+    CIMRGP_REQUIRE(n >= 0 && m >= 0 && ldk >= n && ldb >= n, fn, "bad dimensions");
+    CIMRGP_REQUIRE(dtype == CIMRGP_F32 || dtype == CIMRGP_F64, fn, "unknown dtype");
+    CIMRGP_REQUIRE(ld_ok(dtype, ldk) && ld_ok(dtype, ldb), fn, "leading dimensions must be multiples of 16 bytes");
+    CIMRGP_REQUIRE(aligned16(k_dev) && aligned16(workspace_dev) && aligned16(b_dev), fn, "pointers must be 16-byte aligned");
+    CIMRGP_REQUIRE(workspace_bytes >= cimrgp_potrf_workspace_bytes(dtype, n), fn, "workspace too small");
+    if (n == 0) return check_hip(hipMemsetAsync(info_dev, 0, sizeof(int32_t), S(stream)), fn, "memset");
+    DISPATCH(dtype, fn,
+             potrf_run<float>((float*)k_dev, n, ldk, (float*)workspace_dev, info_dev, (float*)b_dev, m, ldb, S(stream)),
+             potrf_run<double>((double*)k_dev, n, ldk, (double*)workspace_dev, info_dev, (double*)b_dev, m, ldb, S(stream)));
 }
 
 int cimrgp_potrs(int dtype, const void* l_dev, int64_t n, int64_t ldl, const void* workspace_dev, void* rhs_dev, int q,
@@ -107,9 +123,22 @@ int cimrgp_potrs(int dtype, const void* l_dev, int64_t n, int64_t ldl, const voi
     CIMRGP_REQUIRE(n >= 0 && ldl >= n, fn, "bad dimensions");
     DISPATCH(dtype, fn,
              potrs_run<float>((const float*)l_dev, n, ldl, (const float*)workspace_dev, (float*)rhs_dev, q, (float*)z_dev,
-                              (float*)scratch_dev, S(stream)),
+                              (float*)scratch_dev, false, S(stream)),
              potrs_run<double>((const double*)l_dev, n, ldl, (const double*)workspace_dev, (double*)rhs_dev, q,
-                               (double*)z_dev, (double*)scratch_dev, S(stream)));
+                               (double*)z_dev, (double*)scratch_dev, false, S(stream)));
+}
+
+int cimrgp_solve_lt(int dtype, const void* l_dev, int64_t n, int64_t ldl, const void* workspace_dev, void* z_dev, int q,
+                    void* scratch_dev, void* stream)
+{
+    const char* fn = "cimrgp_solve_lt";
+    CIMRGP_REQUIRE(l_dev && workspace_dev && z_dev && scratch_dev, fn, "null pointer");
+    CIMRGP_REQUIRE(n >= 0 && ldl >= n, fn, "bad dimensions");
+    DISPATCH(dtype, fn,
+             potrs_run<float>((const float*)l_dev, n, ldl, (const float*)workspace_dev, (float*)z_dev, q, nullptr,
+                              (float*)scratch_dev, true, S(stream)),
+             potrs_run<double>((const double*)l_dev, n, ldl, (const double*)workspace_dev, (double*)z_dev, q, nullptr,
+                               (double*)scratch_dev, true, S(stream)));
 }
 
 int cimrgp_trsm_rows(int dtype, const void* l_dev, int64_t n, int64_t ldl, const void* workspace_dev, void* b_dev,

@@ -100,7 +100,8 @@ template <> __device__ __forceinline__ uint4 neg_chunk<float>(uint4 v)
 
 // --------------------------------------------------------- host launchers ----
 // potrf.hip
-template <typename T> int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, hipStream_t st);
+template <typename T> int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m, int64_t ldb,
+                                    hipStream_t st);
 template <typename T> int solve_rows_run(const T* l, int64_t n, int64_t ld, const T* ws, T* b, int64_t m,
                                          int64_t ldb, hipStream_t st);
 int profile_begin();
@@ -116,7 +117,7 @@ template <typename T> int predict_mean_run(const T* x, int64_t n, int d, const T
                                            double ell, double sf2, const T* bias, T* mean, int accumulate, hipStream_t st);
 // solve.hip
 template <typename T> int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* z_out, T* scratch,
-                                    hipStream_t st);
+                                    bool backward_only, hipStream_t st);
 template <typename T> int predict_from_w_run(const T* w, int64_t ns, int64_t n, int64_t ldw, const T* z, int q, double sf2,
                                              double extra, const T* bias, T* mean, T* var, int accumulate, hipStream_t st);
 // misc.hip

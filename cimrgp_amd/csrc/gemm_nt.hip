@@ -30,11 +30,10 @@ constexpr int LROW     = KT_BYTES + 16;  // LDS row stride
 // at all (every select on a prefetched register makes hipcc wait for it right behind the
 // load).  EDGE = true: ragged sizes, zero-fill and predicated stores.
 template <typename T, bool LOWER, bool EDGE, int W>
-__global__ __launch_bounds__(256, 2)
-void k_gemm_nt_sub(T* __restrict__ C, int64_t ldc,
-                   const T* __restrict__ A, int64_t lda,
-                   const T* __restrict__ B, int64_t ldb,
-                   int M, int N, int K, int tiles_n)
+static __device__ __forceinline__ void gemm_tile(unsigned char* smem, T* __restrict__ C, int64_t ldc,
+                                                  const T* __restrict__ A, int64_t lda,
+                                                  const T* __restrict__ B, int64_t ldb,
+                                                  int M, int N, int K, int ti, int tj)
 {
     using X = Mx<T>;
     using acc_t = typename X::acc_t;
@@ -42,19 +41,6 @@ void k_gemm_nt_sub(T* __restrict__ C, int64_t ldc,
     constexpr int GT = 32 * W;               // tile edge
     constexpr int NP = GT / 32;              // staging passes (32 rows each)
     constexpr int OP_BYTES = GT * LROW;      // one operand, one stage
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * OP_BYTES];
-
-    int ti, tj;
-    if (LOWER) {
-        const int id = blockIdx.x;
-        ti = (int)((sqrtf(8.0f * (float)id + 1.0f) - 1.0f) * 0.5f);
-        while (ti * (ti + 1) / 2 > id) --ti;
-        while ((ti + 1) * (ti + 2) / 2 <= id) ++ti;
-        tj = id - ti * (ti + 1) / 2;
-    } else {
-        ti = blockIdx.x / tiles_n;
-        tj = blockIdx.x - ti * tiles_n;
-    }
     const int row0 = ti * GT, col0 = tj * GT;
 
     const int tid  = threadIdx.x;
@@ -203,6 +189,33 @@ void k_gemm_nt_sub(T* __restrict__ C, int64_t ldc,
     STAMP(19);
 }
 
+// One workgroup = one tile.  Whether the tile needs bounds handling is decided per workgroup,
+// so a ragged matrix (e.g. 2050 carried rows) pays for it only in its last row/column of tiles.
+template <typename T, bool LOWER, int W>
+__global__ __launch_bounds__(256, 2)
+void k_gemm_nt_sub(T* __restrict__ C, int64_t ldc,
+                   const T* __restrict__ A, int64_t lda,
+                   const T* __restrict__ B, int64_t ldb,
+                   int M, int N, int K, int tiles_n)
+{
+    constexpr int GT = 32 * W;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * GT * LROW];
+    int ti, tj;
+    if (LOWER) {
+        const int id = blockIdx.x;
+        ti = (int)((sqrtf(8.0f * (float)id + 1.0f) - 1.0f) * 0.5f);
+        while (ti * (ti + 1) / 2 > id) --ti;
+        while ((ti + 1) * (ti + 2) / 2 <= id) ++ti;
+        tj = id - ti * (ti + 1) / 2;
+    } else {
+        ti = blockIdx.x / tiles_n;
+        tj = blockIdx.x - ti * tiles_n;
+    }
+    const bool interior = (ti + 1) * GT <= M && (tj + 1) * GT <= N && (K % (KT_BYTES / (int)sizeof(T))) == 0;
+    if (interior) gemm_tile<T, LOWER, false, W>(smem, C, ldc, A, lda, B, ldb, M, N, K, ti, tj);
+    else          gemm_tile<T, LOWER, true,  W>(smem, C, ldc, A, lda, B, ldb, M, N, K, ti, tj);
+}
+
 }  // namespace
 
 template <typename T, int W>
@@ -212,15 +225,12 @@ static int gemm_launch(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, i
     const char* fn = "gemm_nt_sub";
     constexpr int GT = 32 * W;
     const int64_t tm = (m + GT - 1) / GT, tn = (n + GT - 1) / GT;
-    const bool edge = (m % GT) != 0 || (n % GT) != 0 || (k % (KT_BYTES / (int)sizeof(T))) != 0;
     const int64_t tiles = lower ? tm * (tm + 1) / 2 : tm * tn;
     CIMRGP_REQUIRE(tiles < (1ll << 31), fn, "grid too large");
-#define CIMRGP_GEMM_GO(LO_, ED_)                                                                   \
-    hipLaunchKernelGGL((k_gemm_nt_sub<T, LO_, ED_, W>), dim3((unsigned)tiles), dim3(256), 0, st,  \
-                       c, ldc, a, lda, b, ldb, (int)m, (int)n, k, (int)tn)
-    if (lower) { if (edge) CIMRGP_GEMM_GO(true, true);  else CIMRGP_GEMM_GO(true, false); }
-    else       { if (edge) CIMRGP_GEMM_GO(false, true); else CIMRGP_GEMM_GO(false, false); }
-#undef CIMRGP_GEMM_GO
+    if (lower) hipLaunchKernelGGL((k_gemm_nt_sub<T, true, W>), dim3((unsigned)tiles), dim3(256), 0, st,
+                                  c, ldc, a, lda, b, ldb, (int)m, (int)n, k, (int)tn);
+    else       hipLaunchKernelGGL((k_gemm_nt_sub<T, false, W>), dim3((unsigned)tiles), dim3(256), 0, st,
+                                  c, ldc, a, lda, b, ldb, (int)m, (int)n, k, (int)tn);
     CIMRGP_LAUNCH_CHECK(fn);
     return 0;
 }

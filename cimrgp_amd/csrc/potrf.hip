@@ -596,7 +596,7 @@ static int panel_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info,
 // ---------------------------------------------------------------------------
 namespace {
 struct LookAhead {
-    hipStream_t side = nullptr;
+    hipStream_t side = nullptr;        // panel chain (high priority)
     std::vector<hipEvent_t> ev;
     int device = -1;
 };
@@ -669,18 +669,23 @@ static int build_invT(const T* kmat, int64_t n, int64_t ld, T* ws, hipStream_t s
     do { hipError_t e__ = (call); if (e__ != hipSuccess) return check_hip(e__, "cimrgp_potrf", what); } while (0)
 
 template <typename T>
-int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, hipStream_t st)
+int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m, int64_t ldb, hipStream_t st)
 {
+    const bool rows = (b != nullptr && m > 0);
     CIMRGP_HIP_TRY(hipMemsetAsync(info, 0, sizeof(int32_t), st), "hipMemsetAsync(info)");
     const int64_t npanels = (n + CIMRGP_NB - 1) / CIMRGP_NB;
     LookAhead* la = (npanels > 2) ? lookahead_ctx((size_t)(2 * npanels + 2)) : nullptr;
     if (la == nullptr) {
-        int rc0 = panel_sweep<T, true>(k, n, ld, ws, info, nullptr, 0, 0, st);
+        int rc0 = panel_sweep<T, true>(k, n, ld, ws, info, b, m, ldb, st);
         return rc0 ? rc0 : build_invT<T>(k, n, ld, ws, st);
     }
 
     hipStream_t sp = la->side;
     size_t ne = 0;
+    // The caller's stream does the "head" update, the trailing update and -- off the panel
+    // chain -- the carried rows' panel solve + update; the side stream does the latency-bound
+    // panel chain.  (Reserving CUs for the chain with a CU-masked bulk stream was measured and
+    // rejected: a masked queue ran the trailing update 20 % slower even with 8 of 256 CUs masked.)
     int rc = factor_panel<T>(k, n, ld, ws, info, 0, (n < CIMRGP_NB) ? n : CIMRGP_NB, st);
     if (rc) return rc;
     bool side_pending = false;
@@ -688,34 +693,45 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, hipStream_t st)
     for (int64_t k0 = 0; k0 < n; k0 += CIMRGP_NB) {
         const int64_t w  = (n - k0 < CIMRGP_NB) ? (n - k0) : CIMRGP_NB;
         const int64_t k1 = k0 + w;
-        if (k1 >= n) break;
-        const int64_t wn = (n - k1 < CIMRGP_NB) ? (n - k1) : CIMRGP_NB;   // next panel
-        const int64_t k2 = k1 + wn;
         if (side_pending) {                            // panel k0 was factored on the side stream
             CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0), "hipStreamWaitEvent");
             side_pending = false;
         }
-        // head: columns of the next panel, all rows below
-        rc = gemm_nt_sub<T>(k + k1 * ld + k1, ld, k + k1 * ld + k0, ld, k + k1 * ld + k0, ld,
-                            n - k1, wn, (int)w, false, st);
-        if (rc) return rc;
-        hipEvent_t ev_head = la->ev[ne++];
-        CIMRGP_HIP_TRY(hipEventRecord(ev_head, st), "hipEventRecord");
-        // next panel on the side stream, concurrently with the rest of this update
-        CIMRGP_HIP_TRY(hipStreamWaitEvent(sp, ev_head, 0), "hipStreamWaitEvent");
-        rc = factor_panel<T>(k, n, ld, ws, info, k1, wn, sp);
-        if (rc) return rc;
-        ev_panel = la->ev[ne++];
-        CIMRGP_HIP_TRY(hipEventRecord(ev_panel, sp), "hipEventRecord");
-        side_pending = true;
-        // rest: lower SYRK beyond the next panel
-        if (n > k2) {
-            const double mm = (double)(n - k2);
-            TrailRec* rec = rec_open(st, mm * (mm + 1.0) * (double)w);
-            rc = gemm_nt_sub<T>(k + k2 * ld + k2, ld, k + k2 * ld + k0, ld, k + k2 * ld + k0, ld,
-                                n - k2, n - k2, (int)w, true, st);
-            if (rec) (void)hipEventRecord(rec->stop, st);
+        if (k1 < n) {
+            const int64_t wn = (n - k1 < CIMRGP_NB) ? (n - k1) : CIMRGP_NB;   // next panel
+            const int64_t k2 = k1 + wn;
+            // head: columns of the next panel, all rows below
+            rc = gemm_nt_sub<T>(k + k1 * ld + k1, ld, k + k1 * ld + k0, ld, k + k1 * ld + k0, ld,
+                                n - k1, wn, (int)w, false, st);
             if (rc) return rc;
+            hipEvent_t ev_head = la->ev[ne++];
+            CIMRGP_HIP_TRY(hipEventRecord(ev_head, st), "hipEventRecord");
+            // next panel on the side stream, concurrently with the rest of this update
+            CIMRGP_HIP_TRY(hipStreamWaitEvent(sp, ev_head, 0), "hipStreamWaitEvent");
+            rc = factor_panel<T>(k, n, ld, ws, info, k1, wn, sp);
+            if (rc) return rc;
+            ev_panel = la->ev[ne++];
+            CIMRGP_HIP_TRY(hipEventRecord(ev_panel, sp), "hipEventRecord");
+            side_pending = true;
+            // rest: lower SYRK beyond the next panel
+            if (n > k2) {
+                const double mm = (double)(n - k2);
+                TrailRec* rec = rec_open(st, mm * (mm + 1.0) * (double)w);
+                rc = gemm_nt_sub<T>(k + k2 * ld + k2, ld, k + k2 * ld + k0, ld, k + k2 * ld + k0, ld,
+                                    n - k2, n - k2, (int)w, true, st);
+                if (rec) (void)hipEventRecord(rec->stop, st);
+                if (rc) return rc;
+            }
+        }
+        if (rows) {                                    // panel k0 is final: solve + update the carried rows
+            hipLaunchKernelGGL((k_trsm256<T>), dim3((unsigned)((m + TR - 1) / TR)), dim3(256), 0, st,
+                               b + k0, ldb, (int)m, (int)w, (const T*)(k + k0 * ld + k0), ld,
+                               (const T*)(ws + (k0 / SB) * (SB * SB)));
+            CIMRGP_LAUNCH_CHECK("cimrgp_potrf_rows");
+            if (n > k1) {
+                rc = gemm_nt_sub<T>(b + k1, ldb, b + k0, ldb, k + k1 * ld + k0, ld, m, n - k1, (int)w, false, st);
+                if (rc) return rc;
+            }
         }
     }
     if (side_pending) CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0), "hipStreamWaitEvent");
@@ -728,8 +744,8 @@ int solve_rows_run(const T* l, int64_t n, int64_t ld, const T* ws, T* b, int64_t
     return panel_sweep<T, false>(const_cast<T*>(l), n, ld, const_cast<T*>(ws), nullptr, b, m, ldb, st);
 }
 
-template int potrf_run<double>(double*, int64_t, int64_t, double*, int32_t*, hipStream_t);
-template int potrf_run<float>(float*, int64_t, int64_t, float*, int32_t*, hipStream_t);
+template int potrf_run<double>(double*, int64_t, int64_t, double*, int32_t*, double*, int64_t, int64_t, hipStream_t);
+template int potrf_run<float>(float*, int64_t, int64_t, float*, int32_t*, float*, int64_t, int64_t, hipStream_t);
 template int solve_rows_run<double>(const double*, int64_t, int64_t, const double*, double*, int64_t, int64_t, hipStream_t);
 template int solve_rows_run<float>(const float*, int64_t, int64_t, const float*, float*, int64_t, int64_t, hipStream_t);
 

@@ -285,7 +285,8 @@ void k_predict_from_w(const T* __restrict__ W, int ns, int n, int64_t ldw, const
     }
 
 template <typename T>
-int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* z_out, T* scratch, hipStream_t st)
+int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* z_out, T* scratch,
+              bool backward_only, hipStream_t st)
 {
     const char* fn = "cimrgp_potrs";
     if (n <= 0) return 0;
@@ -297,7 +298,7 @@ int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* 
     hipLaunchKernelGGL((k_transpose_nq<T>), dim3(tg), dim3(256), 0, st, (const T*)rhs, work, n, q, 1);
     CIMRGP_LAUNCH_CHECK(fn);
     const T* invT = ws + ((n + SB - 1) / SB) * (SB * SB);
-    for (int64_t k0 = 0; k0 < n; k0 += PW) {
+    for (int64_t k0 = 0; k0 < n && !backward_only; k0 += PW) {
         const int w = (int)((n - k0 < PW) ? (n - k0) : PW);
         const int64_t below = n - (k0 + w);
         const unsigned grid = (unsigned)((below + 63) / 64);
@@ -305,12 +306,14 @@ int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* 
                                               invT, work, res, q, (int)k0, w));
         CIMRGP_LAUNCH_CHECK(fn);
     }
-    if (z_out) {
-        hipLaunchKernelGGL((k_transpose_nq<T>), dim3(tg), dim3(256), 0, st, (const T*)res, z_out, n, q, 0);
-        CIMRGP_LAUNCH_CHECK(fn);
-    }
-    hipError_t e = hipMemcpyAsync(work, res, sizeof(T) * (size_t)(q * n), hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return check_hip(e, fn, "hipMemcpyAsync");
+    if (!backward_only) {
+        if (z_out) {
+            hipLaunchKernelGGL((k_transpose_nq<T>), dim3(tg), dim3(256), 0, st, (const T*)res, z_out, n, q, 0);
+            CIMRGP_LAUNCH_CHECK(fn);
+        }
+        hipError_t e = hipMemcpyAsync(work, res, sizeof(T) * (size_t)(q * n), hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return check_hip(e, fn, "hipMemcpyAsync");
+    }   // backward_only: `work` already holds z (RHS-major), put there by the first transpose
     const int64_t last = ((n - 1) / PW) * PW;
     for (int64_t k0 = last; k0 >= 0; k0 -= PW) {
         const int w = (int)((n - k0 < PW) ? (n - k0) : PW);
@@ -338,8 +341,8 @@ int predict_from_w_run(const T* w, int64_t ns, int64_t n, int64_t ldw, const T* 
     return 0;
 }
 
-template int potrs_run<double>(const double*, int64_t, int64_t, const double*, double*, int, double*, double*, hipStream_t);
-template int potrs_run<float>(const float*, int64_t, int64_t, const float*, float*, int, float*, float*, hipStream_t);
+template int potrs_run<double>(const double*, int64_t, int64_t, const double*, double*, int, double*, double*, bool, hipStream_t);
+template int potrs_run<float>(const float*, int64_t, int64_t, const float*, float*, int, float*, float*, bool, hipStream_t);
 template int predict_from_w_run<double>(const double*, int64_t, int64_t, int64_t, const double*, int, double, double,
                                         const double*, double*, double*, int, hipStream_t);
 template int predict_from_w_run<float>(const float*, int64_t, int64_t, int64_t, const float*, int, double, double,

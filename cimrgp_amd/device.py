@@ -45,8 +45,13 @@ def _p(t):
 
 
 def padded_ld(n):
-    """Row pitch (elements): multiple of 16 so every row starts on a 128-byte line."""
-    return max(16, (int(n) + 15) // 16 * 16)
+    """Row pitch (elements): a multiple of 16 (every row starts on a 128-byte line) that is NOT a
+    multiple of 512 elements: with a power-of-two pitch all rows of a tile start in the same HBM
+    channel / cache set and the strided tile accesses of the update kernels serialise there."""
+    ld = max(16, (int(n) + 15) // 16 * 16)
+    if ld % 512 == 0:
+        ld += 16
+    return ld
 
 
 def alloc_matrix(rows, cols, dtype, device):
@@ -101,6 +106,28 @@ def potrf(kbuf, n, ws=None, info=None):
     _lib.check(lib.cimrgp_potrf(_DT[kbuf.dtype], _p(kbuf), int(n), kbuf.stride(0), _p(ws), ws.numel(),
                                 _p(info), _stream()), "cimrgp_potrf")
     return ws, info
+
+
+def potrf_rows(kbuf, n, bbuf, m, ws=None, info=None):
+    """D2 with m carried rows: kbuf[:n,:n] = L L^T in place and bbuf[:m,:n] <- bbuf L^-T."""
+    lib = _lib.load()
+    if ws is None:
+        ws = potrf_workspace(n, kbuf.dtype, kbuf.device)
+    if info is None:
+        info = torch.zeros(1, dtype=torch.int32, device=kbuf.device)
+    _lib.check(lib.cimrgp_potrf_rows(_DT[kbuf.dtype], _p(kbuf), int(n), kbuf.stride(0), _p(ws), ws.numel(),
+                                     _p(info), _p(bbuf), int(m), bbuf.stride(0), _stream()), "cimrgp_potrf_rows")
+    return ws, info
+
+
+def solve_lt(lbuf, n, ws, z):
+    """Backward half of D3: z (n x q) = L^-1 R is overwritten with alpha = L^-T z."""
+    lib = _lib.load()
+    q = z.shape[1]
+    scratch = torch.empty(2 * q * max(int(n), 1), dtype=lbuf.dtype, device=lbuf.device)
+    _lib.check(lib.cimrgp_solve_lt(_DT[lbuf.dtype], _p(lbuf), int(n), lbuf.stride(0), _p(ws), _p(z), q,
+                                   _p(scratch), _stream()), "cimrgp_solve_lt")
+    return z
 
 
 def raise_if_not_pd(info):

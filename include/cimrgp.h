@@ -77,6 +77,16 @@ int cimrgp_potrf(int dtype, void* k_dev, int64_t n, int64_t ldk,
                  void* workspace_dev, size_t workspace_bytes,
                  int32_t* info_dev, void* stream);
 
+/* Factorisation that carries m extra rows through the same panel sweep:
+ *   K = L L^T  and  B <- B L^-T   (B: m x n row-major, ldb >= n)
+ * in one pass (the row updates fill the compute units the latency-bound panel
+ * chain leaves idle).  With B = [K(X*, X); R^T] this yields W = K* L^-T for D5
+ * and z^T = (L^-1 R)^T for D3 without a separate forward solve. */
+int cimrgp_potrf_rows(int dtype, void* k_dev, int64_t n, int64_t ldk,
+                      void* workspace_dev, size_t workspace_bytes,
+                      int32_t* info_dev, void* b_dev, int64_t m, int64_t ldb,
+                      void* stream);
+
 /* ---- D3: alpha = (L L^T)^-1 R  for q right-hand sides ---------------------
  * Replaces the two triangular solves of GPy's posterior ("woodbury vector").
  * rhs_dev: (n x q) row-major, overwritten with alpha.  z_dev (optional, may
@@ -85,6 +95,12 @@ int cimrgp_potrf(int dtype, void* k_dev, int64_t n, int64_t ldk,
 int cimrgp_potrs(int dtype, const void* l_dev, int64_t n, int64_t ldl,
                  const void* workspace_dev, void* rhs_dev, int q,
                  void* z_dev, void* scratch_dev, void* stream);
+
+/* Backward half only: z_dev (n x q) holds z = L^-1 R and is overwritten with
+ * alpha = L^-T z.  scratch_dev: 2*q*n elements. */
+int cimrgp_solve_lt(int dtype, const void* l_dev, int64_t n, int64_t ldl,
+                    const void* workspace_dev, void* z_dev, int q,
+                    void* scratch_dev, void* stream);
 
 /* Row-wise triangular solve with many right-hand sides (MFMA):
  *   B <- B L^-T      B: (m x n) row-major, ldb >= n,  i.e. row i of B becomes

@@ -183,6 +183,33 @@ def test_predict_mean_and_variance(dev, dt, tol, n, ns, d):
     assert float(np.max(np.abs(var.double().cpu().numpy() - vref))) / sf2 < tol
 
 
+@pytest.mark.parametrize("dt,tol", [("f64", 1e-9), ("f32", 5e-3)])
+@pytest.mark.parametrize("n,m,q", [(64, 5, 2), (300, 70, 1), (777, 130, 2), (1100, 260, 3)])
+def test_potrf_rows_carries_rhs_rows(dev, dt, tol, n, m, q):
+    """One sweep: K = L L^T and [K*; r^T] <- [K*; r^T] L^-T, then the backward-only solve."""
+    x, y = _data(n, 2, seed=n, q=max(q, 2))
+    y = y[:, :q]
+    xs, _ = _data(m, 2, seed=n + 3)
+    ell, sf2, noise = 0.5, 1.1, 0.02
+    tdt = getattr(torch, TDT[dt])
+    xd = dev.to_device(x, tdt, "cuda")
+    kbuf = dev.rbf_gram(xd, ell, sf2, noise, lower_only=True)
+    rows = dev.alloc_matrix(m + q, n, tdt, "cuda")
+    dev.rbf_cross(dev.to_device(xs, tdt, "cuda"), xd, ell, sf2, out=rows)
+    rows[m:m + q, :n] = dev.to_device(y, tdt, "cuda").t()
+    ws, info = dev.potrf_rows(kbuf, n, rows, m + q)
+    assert int(info.item()) == 0
+    fit = oracle.block_fit(x, y, ell, sf2, noise)
+    wref = sla.solve_triangular(fit["L"], oracle.rbf_gram(xs, x, ell, sf2).T, lower=True).T
+    got = rows[:m + q, :n].double().cpu().numpy()
+    assert _relerr(got[:m], wref) < tol
+    assert _relerr(got[m:].T, fit["z"]) < tol
+    assert _relerr(np.tril(kbuf[:n, :n].double().cpu().numpy()), fit["L"]) < tol
+    z = rows[m:m + q, :n].t().contiguous()
+    alpha = dev.solve_lt(kbuf, n, ws, z)
+    assert _relerr(alpha.double().cpu().numpy(), fit["alpha"]) < tol
+
+
 def test_residual_chain_helpers(dev):
     rng = np.random.default_rng(3)
     n, q = 1000, 2

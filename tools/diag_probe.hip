@@ -78,5 +78,45 @@ int main()
             }
         }
     }
+    {   // rectangular update of carried rows: M = 2048 rows x N columns, K = 256
+        const int nn = 8192; const int64_t l2 = 8208;
+        double *dA, *dB2; hipMalloc(&dA, (size_t)nn * l2 * 8); hipMemset(dA, 0, (size_t)nn * l2 * 8);
+        hipMalloc(&dB2, (size_t)2048 * l2 * 8); hipMemset(dB2, 0, (size_t)2048 * l2 * 8);
+        for (int N : {7936, 4096, 2048}) {
+            float best = 1e9f;
+            for (int rep = 0; rep < 3; ++rep) {
+                hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+                hipEventRecord(e0);
+                gemm_nt_sub<double>(dB2 + 256, l2, dB2, l2, dA + 256 * l2, l2, 2048, N, 256, false, 0);
+                hipEventRecord(e1); hipDeviceSynchronize();
+                float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+            }
+            printf("rect gemm M=2048 N=%d: %.1f us  (%.1f TF/s)\n", N, best * 1e3, 2.0 * 2048 * N * 256 / (best * 1e-3) / 1e12);
+        }
+    }
+    {   // CU-masked streams: does the trailing update keep its rate on a subset of the CUs?
+        const int nn = 8192; const int64_t l2 = 8192;
+        double* dA; hipMalloc(&dA, (size_t)nn * l2 * 8); hipMemset(dA, 0, (size_t)nn * l2 * 8);
+        for (int pat = 0; pat < 5; ++pat) {
+            uint32_t mask[8]; for (int i = 0; i < 8; ++i) mask[i] = 0xffffffffu;
+            const char* name = "all CUs";
+            if (pat == 1) { mask[0] = 0; name = "bits 0-31 off"; }
+            if (pat == 2) { for (int i = 0; i < 8; ++i) mask[i] = 0xfffffffeu; name = "bit 0 of every word off"; }
+            if (pat == 3) { for (int i = 0; i < 8; ++i) mask[i] = 0xfffefffeu; name = "bits 0,16 of every word off"; }
+            if (pat == 4) { mask[0] = 0; mask[1] = 0; name = "bits 0-63 off"; }
+            hipStream_t sm;
+            if (hipExtStreamCreateWithCUMask(&sm, 8, mask) != hipSuccess) { printf("mask stream failed\n"); continue; }
+            float best = 1e9f;
+            for (int rep = 0; rep < 3; ++rep) {
+                hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+                hipEventRecord(e0, sm);
+                gemm_nt_sub<double>(dA + 256 * l2 + 256, l2, dA + 256 * l2, l2, dA + 256 * l2, l2, 7936, 7936, 256, true, sm);
+                hipEventRecord(e1, sm); hipStreamSynchronize(sm);
+                float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+            }
+            printf("masked gemm M=7936 [%s]: %.1f us\n", name, best * 1e3);
+            hipStreamDestroy(sm);
+        }
+    }
     return 0;
 }
