@@ -6,8 +6,12 @@
 labels (population std) done by the base class.  ``GP_RBF`` replaces the
 GPy-backed subclass (RegressionInput.py:55-67) with the HIP kernels: isotropic
 RBF (GPy defaults l = 1, variance = 1 on the z-scored inputs), Gaussian noise
-``labels.var() * 0.01`` on the z-scored labels; hyper-parameters are FIXED
-(``model.optimize()``, RegressionInput.py:63, is listed as next in SURVEY 8f).
+``labels.var() * 0.01`` on the z-scored labels.  ``optimize=True`` reproduces the
+``model.optimize()`` step (RegressionInput.py:63): L-BFGS-B (SciPy, the optimiser GPy's
+default ``'lbfgsb'`` wraps) on the log marginal likelihood over (variance, length-scale,
+noise), all constrained positive through a log transform, starting from those defaults;
+objective and gradient are evaluated on the GPU (one Cholesky, K^-1 = L^-T L^-1 through the
+MFMA kernels, one fused reduction for the gradient).  Default is fixed hyper-parameters.
 """
 import abc
 
@@ -67,12 +71,59 @@ class RegressionMethod(object):
 class GP_RBF(RegressionMethod):
     name = 'GP_RBF'
 
-    def __init__(self, lengthscale=1., variance=1., dtype='f64', device=None):
+    def __init__(self, lengthscale=1., variance=1., dtype='f64', device=None, optimize=False, max_iters=1000):
         super(GP_RBF, self).__init__()
         self.kernel = RBFKernel(l=lengthscale, sf=variance)
         self.dtype = dev.as_torch_dtype(dtype)
         self.device = device
         self.block = None
+        self.optimize = optimize
+        self.max_iters = max_iters
+        self.optimizer_result = None
+
+    # ---- log marginal likelihood and its gradient, on the GPU ----------------------------
+    def log_marginal_likelihood(self, x, y, ell, sf, noise, want_grad=True):
+        """LML of targets y (device, n x q) under K = sf E(ell) + noise I, and its gradient
+        w.r.t. (log sf, log ell, log noise).  Raises LinAlgError if K is not PD."""
+        n, q = y.shape
+        kbuf = dev.rbf_gram(x, ell, sf, noise, lower_only=True)
+        ws, info = dev.potrf(kbuf, n)
+        alpha = y.clone()
+        dev.potrs(kbuf, n, ws, alpha)
+        dev.raise_if_not_pd(info)
+        half_logdet = float(dev.logdet_half(kbuf, n).item())
+        fit = float((y * alpha).sum().item())
+        lml = -0.5 * fit - q * half_logdet - 0.5 * n * q * np.log(2 * np.pi)
+        if not want_grad:
+            return lml, None
+        # K^-1 = U U^T with U = L^-T: the identity carried through the row-wise solve, then a SYRK
+        u = dev.alloc_matrix(n, n, x.dtype, x.device)
+        u.zero_()
+        u[:n, :n].fill_diagonal_(1.0)
+        dev.trsm_rows(kbuf, n, ws, u, n)
+        kinv = dev.alloc_matrix(n, n, x.dtype, x.device)
+        kinv.zero_()
+        dev.syrk_lower(kinv, u, n, n)            # lower(kinv) = -K^-1
+        kinv.neg_()
+        grad = dev.lml_grad(x, kinv, n, alpha, ell, sf, noise).cpu().numpy()
+        return lml, grad
+
+    def _optimize(self, x, y, noise0):
+        from scipy.optimize import minimize
+        theta0 = np.log([self.kernel.sf, self.kernel.l, noise0])
+
+        def objective(theta):
+            sf, ell, noise = np.exp(theta)
+            try:
+                lml, grad = self.log_marginal_likelihood(x, y, ell, sf, noise)
+            except np.linalg.LinAlgError:
+                return 1e100, np.zeros(3)
+            return -lml, -grad
+
+        res = minimize(objective, theta0, jac=True, method='L-BFGS-B', options=dict(maxiter=self.max_iters))
+        self.optimizer_result = res
+        sf, ell, noise = np.exp(res.x)
+        self.kernel = RBFKernel(l=float(ell), sf=float(sf), noise=float(noise))
 
     def _fit(self, train_data):
         inputs, labels = train_data
@@ -83,6 +134,8 @@ class GP_RBF(RegressionMethod):
         self.kernel.noise = float(labels.var()) * NOISE_FRACTION
         x = dev.to_device(inputs, self.dtype, device)
         y = dev.to_device(labels, self.dtype, device)
+        if self.optimize:
+            self._optimize(x, y, self.kernel.noise)
         self.block = DenseBlock(x, self.kernel)
         zero_bias = torch.zeros(y.shape[1], dtype=self.dtype, device=device)
         sink = torch.zeros_like(y)

@@ -35,6 +35,9 @@ SIGNATURES = {
     "cimrgp_add_diag": (_i32, [_i32, _vp, _i64, _i64, _vp, _vp]),
     "cimrgp_noise_from_stats": (_i32, [_i32, _vp, _i32, _dbl, _dbl, _vp, _vp]),
     "cimrgp_logdet_half": (_i32, [_i32, _vp, _i64, _i64, _vp, _vp]),
+    "cimrgp_syrk_lower": (_i32, [_i32, _vp, _i64, _vp, _i64, _i64, _i64, _vp]),
+    "cimrgp_lml_grad_scratch_bytes": (_sz, [_i64]),
+    "cimrgp_lml_grad": (_i32, [_i32, _vp, _i64, _i32, _vp, _i64, _vp, _i32, _dbl, _dbl, _dbl, _vp, _vp, _vp]),
     "cimrgp_profile_begin": (_i32, []),
     "cimrgp_profile_collect": (_i32, [C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_i64)]),
 }

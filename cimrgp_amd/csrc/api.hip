@@ -248,6 +248,38 @@ int cimrgp_logdet_half(int dtype, const void* l_dev, int64_t n, int64_t ldl, dou
              misc_logdet_half<double>((const double*)l_dev, n, ldl, out_dev, S(stream)));
 }
 
+int cimrgp_syrk_lower(int dtype, void* c_dev, int64_t ldc, const void* a_dev, int64_t lda, int64_t n, int64_t k, void* stream)
+{
+    const char* fn = "cimrgp_syrk_lower";
+    CIMRGP_REQUIRE(c_dev && a_dev, fn, "null pointer");
+    CIMRGP_REQUIRE(n >= 0 && k >= 0 && ldc >= n && lda >= k && k < (1ll << 31), fn, "bad dimensions");
+    CIMRGP_REQUIRE(dtype == CIMRGP_F32 || dtype == CIMRGP_F64, fn, "unknown dtype");
+    DISPATCH(dtype, fn,
+             gemm_nt_sub<float>((float*)c_dev, ldc, (const float*)a_dev, lda, (const float*)a_dev, lda, n, n, (int)k, true, S(stream)),
+             gemm_nt_sub<double>((double*)c_dev, ldc, (const double*)a_dev, lda, (const double*)a_dev, lda, n, n, (int)k, true,
+                                 S(stream)));
+}
+
+int cimrgp_lml_grad(int dtype, const void* x_dev, int64_t n, int d, const void* kinv_dev, int64_t ldk, const void* alpha_dev,
+                    int q, double ell, double sf2, double noise, double* out_dev, double* scratch_dev, void* stream)
+{
+    const char* fn = "cimrgp_lml_grad";
+    CIMRGP_REQUIRE(x_dev && kinv_dev && alpha_dev && out_dev && scratch_dev, fn, "null pointer");
+    CIMRGP_REQUIRE(ldk >= n, fn, "bad dimensions");
+    DISPATCH(dtype, fn,
+             lml_grad_run<float>((const float*)x_dev, n, d, (const float*)kinv_dev, ldk, (const float*)alpha_dev, q, ell, sf2,
+                                 noise, out_dev, scratch_dev, S(stream)),
+             lml_grad_run<double>((const double*)x_dev, n, d, (const double*)kinv_dev, ldk, (const double*)alpha_dev, q, ell,
+                                  sf2, noise, out_dev, scratch_dev, S(stream)));
+}
+
+size_t cimrgp_lml_grad_scratch_bytes(int64_t n)
+{
+    if (n <= 0) return 0;
+    const int64_t tm = (n + 63) / 64;
+    return (size_t)(tm * (tm + 1) / 2) * 3 * sizeof(double);
+}
+
 int cimrgp_profile_begin(void) { return profile_begin(); }
 
 int cimrgp_profile_collect(double* total_ms, double* total_flops, int64_t* launches)

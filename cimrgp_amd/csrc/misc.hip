@@ -177,3 +177,117 @@ CIMRGP_INST(float)
 #undef CIMRGP_INST
 
 }  // namespace cimrgp
+
+// ---------------------------------------------------------------------------
+// Gradient of the log marginal likelihood (the `.optimize()` step of
+// RegressionInput.py:63).  With G = alpha alpha^T - q K^-1 and the RBF parametrisation
+// K = sf E + noise I,  E_ij = exp(-d2_ij / (2 l^2)):
+//     dLML/dlog(sf)    = 1/2 sum_ij G_ij sf E_ij
+//     dLML/dlog(l)     = 1/2 sum_ij G_ij sf E_ij d2_ij / l^2
+//     dLML/dlog(noise) = 1/2 noise sum_i G_ii
+// One pass over the LOWER triangle of K^-1 (off-diagonal entries count twice); the kernel
+// matrix is re-evaluated on the fly from X, nothing n x n besides K^-1 is read.  Per-tile
+// partial sums, then a fixed-order final reduction (deterministic).
+// ---------------------------------------------------------------------------
+namespace cimrgp {
+namespace {
+
+constexpr int LG_T = 64;
+constexpr int LG_MAXD = 8;
+
+template <typename T>
+__global__ __launch_bounds__(256)
+void k_lml_grad_tiles(const T* __restrict__ x, int n, int d, const T* __restrict__ kinv, int64_t ld,
+                      const T* __restrict__ alpha, int q, T neg_half_inv_l2, T sf2, T inv_l2,
+                      double* __restrict__ partial)
+{
+    __shared__ T sa[LG_T * LG_MAXD], sb[LG_T * LG_MAXD];
+    __shared__ T aa[LG_T * 8], ab[LG_T * 8];
+    __shared__ double red[3][4];
+    const int id = blockIdx.x;
+    int ti = (int)((sqrtf(8.0f * (float)id + 1.0f) - 1.0f) * 0.5f);
+    while (ti * (ti + 1) / 2 > id) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= id) ++ti;
+    const int tj = id - ti * (ti + 1) / 2;
+    const int row0 = ti * LG_T, col0 = tj * LG_T;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < LG_T * LG_MAXD; e += 256) {
+        const int r = e / LG_MAXD, k = e - r * LG_MAXD;
+        sa[e] = (k < d && row0 + r < n) ? x[(int64_t)(row0 + r) * d + k] : (T)0;
+        sb[e] = (k < d && col0 + r < n) ? x[(int64_t)(col0 + r) * d + k] : (T)0;
+        aa[e] = (k < q && row0 + r < n) ? alpha[(int64_t)(row0 + r) * q + k] : (T)0;
+        ab[e] = (k < q && col0 + r < n) ? alpha[(int64_t)(col0 + r) * q + k] : (T)0;
+    }
+    __syncthreads();
+    const int tx = tid & 63, ty = tid >> 6;
+    double s_sf = 0.0, s_l = 0.0, s_tr = 0.0;
+    const int gc = col0 + tx;
+    for (int rr = ty; rr < LG_T; rr += 4) {
+        const int gr = row0 + rr;
+        if (gr < n && gc < n && gc <= gr) {
+            T d2 = (T)0;
+#pragma unroll
+            for (int k = 0; k < LG_MAXD; ++k) {
+                const T df = sa[rr * LG_MAXD + k] - sb[tx * LG_MAXD + k];
+                d2 += df * df;
+            }
+            T aat = (T)0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) aat += aa[rr * 8 + k] * ab[tx * 8 + k];
+            const T g = aat - (T)q * kinv[(int64_t)gr * ld + gc];
+            const T kf = sf2 * exp(d2 * neg_half_inv_l2);
+            const double wgt = (gr == gc) ? 1.0 : 2.0;
+            s_sf += wgt * (double)(g * kf);
+            s_l  += wgt * (double)(g * kf * d2 * inv_l2);
+            if (gr == gc) s_tr += (double)g;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s_sf += __shfl_xor(s_sf, off, 64);
+        s_l  += __shfl_xor(s_l, off, 64);
+        s_tr += __shfl_xor(s_tr, off, 64);
+    }
+    if (tx == 0) { red[0][ty] = s_sf; red[1][ty] = s_l; red[2][ty] = s_tr; }
+    __syncthreads();
+    if (tid < 3) partial[(int64_t)id * 3 + tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+}
+
+__global__ __launch_bounds__(1024)
+void k_lml_grad_final(const double* __restrict__ partial, int64_t ntiles, double noise, double* __restrict__ out)
+{
+    __shared__ double red[16];
+    for (int c = 0; c < 3; ++c) {
+        double s = 0.0;
+        for (int64_t t = threadIdx.x; t < ntiles; t += blockDim.x) s += partial[t * 3 + c];
+        s = block_sum_1024(s, red);
+        if (threadIdx.x == 0) out[c] = 0.5 * s * (c == 2 ? noise : 1.0);
+    }
+}
+
+}  // namespace
+
+template <typename T>
+int lml_grad_run(const T* x, int64_t n, int d, const T* kinv, int64_t ld, const T* alpha, int q,
+                 double ell, double sf2, double noise, double* out3, double* scratch, hipStream_t st)
+{
+    const char* fn = "cimrgp_lml_grad";
+    CIMRGP_REQUIRE(n > 0 && n < (1ll << 30), fn, "bad size");
+    CIMRGP_REQUIRE(d >= 1 && d <= LG_MAXD, fn, "input dimension must be in [1, 8]");
+    CIMRGP_REQUIRE(q >= 1 && q <= 8, fn, "number of outputs must be in [1, 8]");
+    const int64_t tm = (n + LG_T - 1) / LG_T, tiles = tm * (tm + 1) / 2;
+    CIMRGP_REQUIRE(tiles < (1ll << 31), fn, "grid too large");
+    hipLaunchKernelGGL((k_lml_grad_tiles<T>), dim3((unsigned)tiles), dim3(256), 0, st, x, (int)n, d, kinv, ld, alpha, q,
+                       (T)(-0.5 / (ell * ell)), (T)sf2, (T)(1.0 / (ell * ell)), scratch);
+    CIMRGP_LAUNCH_CHECK(fn);
+    hipLaunchKernelGGL(k_lml_grad_final, dim3(1), dim3(1024), 0, st, (const double*)scratch, tiles, noise, out3);
+    CIMRGP_LAUNCH_CHECK(fn);
+    return 0;
+}
+
+template int lml_grad_run<double>(const double*, int64_t, int, const double*, int64_t, const double*, int, double, double,
+                                  double, double*, double*, hipStream_t);
+template int lml_grad_run<float>(const float*, int64_t, int, const float*, int64_t, const float*, int, double, double,
+                                 double, double*, double*, hipStream_t);
+
+}  // namespace cimrgp

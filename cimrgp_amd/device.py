@@ -229,3 +229,22 @@ def logdet_half(lbuf, n):
     _lib.check(lib.cimrgp_logdet_half(_DT[lbuf.dtype], _p(lbuf), int(n), lbuf.stride(0), _p(out), _stream()),
                "cimrgp_logdet_half")
     return out
+
+
+def syrk_lower(cbuf, abuf, n, k):
+    """cbuf[:n,:n] (lower) -= abuf[:n,:k] abuf[:n,:k]^T."""
+    lib = _lib.load()
+    _lib.check(lib.cimrgp_syrk_lower(_DT[cbuf.dtype], _p(cbuf), cbuf.stride(0), _p(abuf), abuf.stride(0), int(n), int(k),
+                                     _stream()), "cimrgp_syrk_lower")
+    return cbuf
+
+
+def lml_grad(x, kinv, n, alpha, ell, sf2, noise):
+    """Gradient of the log marginal likelihood w.r.t. (log sf, log l, log noise): device float64[3]."""
+    lib = _lib.load()
+    out = torch.empty(3, dtype=torch.float64, device=x.device)
+    scratch = torch.empty(max(lib.cimrgp_lml_grad_scratch_bytes(int(n)), 8) // 8, dtype=torch.float64, device=x.device)
+    _lib.check(lib.cimrgp_lml_grad(_DT[x.dtype], _p(x), int(n), x.shape[1], _p(kinv), kinv.stride(0), _p(alpha),
+                                   alpha.shape[1], float(ell), float(sf2), float(noise), _p(out), _p(scratch), _stream()),
+               "cimrgp_lml_grad")
+    return out

@@ -161,6 +161,21 @@ int cimrgp_noise_from_stats(int dtype, const void* stats_dev, int q,
 int cimrgp_logdet_half(int dtype, const void* l_dev, int64_t n, int64_t ldl,
                        double* out_dev, void* stream);
 
+/* ---- hyper-parameter optimisation step (RegressionInput.py:63, `.optimize()`) ----
+ * C <- C - A A^T on the lower triangle (C: n x n, A: n x k, row-major).  With C = 0 and
+ * A = L^-T (cimrgp_trsm_rows applied to the identity) this gives -K^-1. */
+int cimrgp_syrk_lower(int dtype, void* c_dev, int64_t ldc, const void* a_dev,
+                      int64_t lda, int64_t n, int64_t k, void* stream);
+/* Gradient of the log marginal likelihood w.r.t. (log sf, log l, log noise) for
+ * K = sf E + noise I:  out_dev[0..2] (doubles) = 1/2 tr((alpha alpha^T - q K^-1) dK/dtheta).
+ * kinv_dev: K^-1 in its lower triangle (n x ldk); alpha_dev (n x q); the kernel matrix is
+ * re-evaluated from x_dev on the fly.  scratch_dev: cimrgp_lml_grad_scratch_bytes(n). */
+size_t cimrgp_lml_grad_scratch_bytes(int64_t n);
+int cimrgp_lml_grad(int dtype, const void* x_dev, int64_t n, int d,
+                    const void* kinv_dev, int64_t ldk, const void* alpha_dev, int q,
+                    double ell, double sf2, double noise, double* out_dev,
+                    double* scratch_dev, void* stream);
+
 /* ---- measurement hooks (bench.py roofline; no reference counterpart) ---------
  * Between begin and collect every lower-triangular trailing-update launch of
  * cimrgp_potrf is bracketed by HIP events on its own stream.  collect waits

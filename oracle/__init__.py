@@ -25,12 +25,12 @@ from .structure import (index_bounds_uniform, index_set_from_bounds,
                         concat_regions, latent_from_coarser, sum_over_layers)
 from .dense import (rbf_gram, block_fit, block_predict, potrf_lower)
 from .mrgp import (DenseLayerSpec, mrgp_fit, mrgp_predict, gp_rbf_fit,
-                   gp_rbf_predict)
+                   gp_rbf_predict, gp_lml_and_grad, gp_rbf_optimize)
 
 __all__ = [
     "index_bounds_uniform", "index_set_from_bounds", "normalize_inputs",
     "zscore_fit", "zscore_apply", "concat_regions", "latent_from_coarser",
     "sum_over_layers", "rbf_gram", "block_fit", "block_predict",
     "potrf_lower", "DenseLayerSpec", "mrgp_fit", "mrgp_predict", "gp_rbf_fit",
-    "gp_rbf_predict",
+    "gp_rbf_predict", "gp_lml_and_grad", "gp_rbf_optimize",
 ]

@@ -137,3 +137,44 @@ def gp_rbf_predict(state, test_inputs, want_var=False):
                               state['sf2'], want_var)
     mean = zscore_apply(state['stats'], inverse_labels=mean)
     return (mean, var) if want_var else mean
+
+
+def gp_lml_and_grad(x, y, ell, sf2, noise):
+    """Log marginal likelihood of an exact GP with K = sf2 E + noise I (q outputs sharing K)
+    and its gradient w.r.t. (log sf2, log ell, log noise) -- Rasmussen & Williams eq. 5.8/5.9.
+    This is the objective GPy's ``model.optimize()`` (RegressionInput.py:63) climbs."""
+    import scipy.linalg as sla
+    from .dense import rbf_gram
+    n, q = y.shape
+    kf = rbf_gram(x, None, ell, sf2, 0.0)
+    k = kf + noise * np.eye(n)
+    chol = sla.cholesky(k, lower=True)
+    alpha = sla.cho_solve((chol, True), y)
+    lml = -0.5 * np.sum(y * alpha) - q * np.sum(np.log(np.diag(chol))) - 0.5 * n * q * np.log(2 * np.pi)
+    kinv = sla.cho_solve((chol, True), np.eye(n))
+    g = alpha @ alpha.T - q * kinv
+    d2 = -2.0 * ell * ell * np.log(np.maximum(kf / sf2, 1e-300))
+    grad = np.array([0.5 * np.sum(g * kf), 0.5 * np.sum(g * kf * d2 / (ell * ell)), 0.5 * noise * np.trace(g)])
+    return lml, grad
+
+
+def gp_rbf_optimize(inputs, labels, max_iters=1000):
+    """``GP_RBF().fit`` INCLUDING ``model.optimize()``: L-BFGS-B on -LML over
+    (log sf2, log ell, log noise) from GPy's defaults (1, 1, 0.01 var)."""
+    from scipy.optimize import minimize
+    stats = zscore_fit(inputs, labels)
+    xz, yz = zscore_apply(stats, inputs=inputs, labels=labels)
+    theta0 = np.log([1.0, 1.0, float(yz.var()) * NOISE_FRACTION])
+
+    def objective(theta):
+        sf2, ell, noise = np.exp(theta)
+        try:
+            lml, grad = gp_lml_and_grad(xz, yz, ell, sf2, noise)
+        except np.linalg.LinAlgError:
+            return 1e100, np.zeros(3)
+        return -lml, -grad
+
+    res = minimize(objective, theta0, jac=True, method='L-BFGS-B', options=dict(maxiter=max_iters))
+    sf2, ell, noise = np.exp(res.x)
+    fit = block_fit(xz, yz, ell, sf2, noise)
+    return dict(stats=stats, xz=xz, fit=fit, ell=ell, sf2=sf2, noise=noise, result=res)

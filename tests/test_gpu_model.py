@@ -144,3 +144,97 @@ def test_full_size_properties_n8192(ca):
     m = dev.predict_mean(xd, alpha, xd[:512], ell, sf2, None)
     want = (torch.from_numpy(y).cuda() - noise * alpha)[:512]
     assert float((m - want).abs().max()) < 1e-7
+
+
+def _two_rank_worker(rank, world, port, out_dir):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as td
+    import cimrgp_amd as ca
+    # two ranks share the one GPU of the box: gloo carries the (device) tensors; on a multi-GPU
+    # node the same code runs with backend "nccl" (RCCL) and one GPU per rank
+    torch.cuda.set_device(0)
+    td.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    rng = np.random.default_rng(21)
+    n, ns, res = 640, 200, 3
+    x = np.sort(rng.uniform(-2, 2, size=(n, 1)), axis=0)
+    y = np.hstack([np.sin(3 * x), np.cos(5 * x) * x]) + 0.1 * rng.normal(size=(n, 2))
+    xs = np.sort(rng.uniform(-2, 2, size=(ns, 1)), axis=0)
+    kernels = [ca.RBFKernel(l=1.0 / 2 ** j, sf=1.0) for j in range(res + 1)]
+    model = ca.MultiResolutionGaussianProcess([x, y], index_set_obj=ca.IndexSetUniform(n, res, 2),
+                                              spectral_density_obj=kernels)
+    assert (model.rank, model.world_size) == (rank, world)
+    owned = [len(model._owned(j)) for j in range(res + 1)]
+    model.fit()
+    mean, var = model.get_predicted_mean_and_var(xs, ca.IndexSetUniform(ns, res, 2))
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), mean=mean, var=var, owned=np.array(owned),
+             f_bar=model._f_bar_final.cpu().numpy(), x=x, y=y, xs=xs)
+    td.destroy_process_group()
+
+
+def test_two_rank_sharded_model_on_gpu(ca, tmp_path):
+    """N > 1 path end to end on real kernels: blocks sharded over 2 ranks, per-layer residual
+    all-reduce, one fused [mean | var] reduce; every rank must hold the single-process result."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g0 = np.load(os.path.join(str(tmp_path), "rank0.npz"))
+    g1 = np.load(os.path.join(str(tmp_path), "rank1.npz"))
+    x, y, xs = g0["x"], g0["y"], g0["xs"]
+    n, ns, res = x.shape[0], xs.shape[0], 3
+    xn, _, mu, sd = oracle.normalize_inputs(x)
+    specs = [oracle.DenseLayerSpec(1.0 / 2 ** j, 1.0, None) for j in range(res + 1)]
+    omodel, f_bar = oracle.mrgp_fit(xn, y, oracle.index_bounds_uniform(n, res, 2), specs)
+    omean, ovar = oracle.mrgp_predict(xn, omodel, specs, (xs - mu) / sd, oracle.index_bounds_uniform(ns, res, 2))
+    for g in (g0, g1):
+        assert _relerr(g["mean"], omean) < 1e-7
+        assert _relerr(g["var"], ovar) < 1e-6
+        assert _relerr(g["f_bar"], f_bar) < 1e-7
+    # layer 0 has one block (rank 0), finer layers are split evenly
+    assert g0["owned"].tolist() == [1, 1, 2, 4] and g1["owned"].tolist() == [0, 1, 2, 4]
+
+
+@pytest.mark.parametrize("n,d", [(64, 1), (300, 2), (777, 1)])
+def test_log_marginal_likelihood_and_gradient(ca, n, d):
+    """The objective of `model.optimize()` (RegressionInput.py:63) and its gradient on the GPU."""
+    rng = np.random.default_rng(n)
+    x = rng.uniform(-2, 2, size=(n, d))
+    y = np.stack([np.sin(2 * x[:, 0]) + x[:, -1], np.cos(x[:, 0] * x[:, -1])], axis=1) + 0.1 * rng.normal(size=(n, 2))
+    model = ca.GP_RBF()
+    xd = ca.device.to_device(x, torch.float64, "cuda")
+    yd = ca.device.to_device(y, torch.float64, "cuda")
+    for ell, sf, noise in [(1.0, 1.0, 0.01), (0.6, 1.7, 0.1)]:
+        lml, grad = model.log_marginal_likelihood(xd, yd, ell, sf, noise)
+        olml, ograd = oracle.gp_lml_and_grad(x, y, ell, sf, noise)
+        assert abs(lml - olml) < 1e-8 * abs(olml)
+        np.testing.assert_allclose(grad, ograd, rtol=1e-7, atol=1e-7 * np.max(np.abs(ograd)))
+
+
+def test_gp_rbf_optimize_matches_oracle(ca):
+    rng = np.random.default_rng(5)
+    n = 250
+    x = np.sort(rng.uniform(0, 6, size=(n, 1)), axis=0)
+    y = np.hstack([np.sin(2 * x), np.cos(3 * x) + 0.3 * x]) + 0.15 * rng.normal(size=(n, 2))
+    xt = np.linspace(0.1, 5.9, 40)[:, None]
+    model = ca.GP_RBF(optimize=True)
+    assert model.fit([x, y]) is True
+    ref = oracle.gp_rbf_optimize(x, y)
+    # same optimiser, same start, same objective: the optima agree closely
+    got = np.array([model.kernel.l, model.kernel.sf, model.kernel.noise])
+    want = np.array([ref["ell"], ref["sf2"], ref["noise"]])
+    np.testing.assert_allclose(got, want, rtol=1e-3)
+    assert model.optimizer_result.success
+    # the optimum beats the fixed defaults on the marginal likelihood, and predictions agree
+    pred = model.predict(xt)
+    opred = oracle.gp_rbf_predict(ref, xt)
+    assert _relerr(pred, opred) < 1e-4
+    fixed = ca.GP_RBF()
+    fixed.fit([x, y])
+    assert float(np.mean((pred - np.hstack([np.sin(2 * xt), np.cos(3 * xt) + 0.3 * xt])) ** 2)) < \
+        float(np.mean((fixed.predict(xt) - np.hstack([np.sin(2 * xt), np.cos(3 * xt) + 0.3 * xt])) ** 2)) * 1.5
