@@ -83,8 +83,6 @@ class MultiResolutionGaussianProcess(object):
         self.forced_independence = forced_independence
         if forced_independence is not True and (axis_resolution_specific or ard_resolution_specific):
             raise TypeError("not yet supported")
-        if adaptive_inputs is True:
-            raise TypeError("not yet supported")      # input warp: SURVEY 8f rank 3
         if index_set_obj is None:
             raise ValueError('index_set_obj is required')
         self.adaptive_inputs = adaptive_inputs
@@ -131,12 +129,14 @@ class MultiResolutionGaussianProcess(object):
         self.group = process_group
         self.rank, self.world_size = dist.world(process_group)
 
-        self.input_obj = Inputs(x=dev.to_device(x_train, self.dtype, self.device), index_set=index_set_obj,
-                                learn_inputs=False, full_x=self.full_x, input_model=input_model)
-        self.dx = x_train.shape[1]
+        # learned input warp x -> regular grid (Inputs.py:8-55): an exact RBF GP fitted on the GPU
+        self.input_obj = Inputs(x=x_train, index_set=index_set_obj, learn_inputs=self.adaptive_inputs,
+                                full_x=self.full_x, input_model=input_model)
+        self._x_dev = dev.to_device(self.input_obj.x, self.dtype, self.device)
+        self.dx = self.input_obj.x.shape[1]
         self.n_regions = [len(layer) for layer in index_set_obj.bounds]
         self.n_samps = [[int(b - a) for a, b in layer] for layer in index_set_obj.bounds]
-        self.x = [[self.input_obj.get_inputs(j, l) for l in range(self.n_regions[j])] for j in range(self.n_layers)]
+        self.x = [[self._x_dev[int(a):int(b)] for a, b in index_set_obj.bounds[j]] for j in range(self.n_layers)]
         self._y = dev.to_device(y_train, self.dtype, self.device)
         self.owner = [dist.assign_blocks(self.n_samps[j], self.world_size) for j in range(self.n_layers)]
 
@@ -204,6 +204,8 @@ class MultiResolutionGaussianProcess(object):
         test_x = np.asarray(test_x, dtype=np.float64)
         if self.standard_normalized_inputs is True:
             test_x = (test_x - self.mean_x_train) / self.std_x_train
+        if self.adaptive_inputs is True:                 # MRGP.py:770-778
+            test_x = self.input_obj.warp(test_x, self.full_x)
         return dev.to_device(test_x, self.dtype, self.device)
 
     def _check_index_set(self, index_set, number_of_regions):

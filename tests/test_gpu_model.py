@@ -238,3 +238,32 @@ def test_gp_rbf_optimize_matches_oracle(ca):
     fixed.fit([x, y])
     assert float(np.mean((pred - np.hstack([np.sin(2 * xt), np.cos(3 * xt) + 0.3 * xt])) ** 2)) < \
         float(np.mean((fixed.predict(xt) - np.hstack([np.sin(2 * xt), np.cos(3 * xt) + 0.3 * xt])) ** 2)) * 1.5
+
+
+def test_adaptive_inputs_warp(ca):
+    """`adaptive_inputs=True` (both reference scripts use it): inputs are warped onto a regular
+    grid by an exact GP x -> z (Inputs.py:11-22) and test inputs go through the same model
+    (MRGP.py:770-778).  Checked against the oracle fed with the oracle's own warp."""
+    rng = np.random.default_rng(12)
+    n, ns, res = 200, 80, 1
+    x = np.sort(rng.uniform(1, 3, size=(n, 1)) ** 2, axis=0)          # unevenly spaced inputs
+    y = np.hstack([np.sin(2 * x), np.cos(x)]) + 0.05 * rng.normal(size=(n, 2))
+    xs = np.sort(rng.uniform(1.5, 8.5, size=(ns, 1)), axis=0)
+    kernels = [ca.RBFKernel(l=1.0, sf=1.0), ca.RBFKernel(l=0.5, sf=1.0)]
+    model = ca.MultiResolutionGaussianProcess([x, y], index_set_obj=ca.IndexSetUniform(n, res, 2),
+                                              spectral_density_obj=kernels, adaptive_inputs=True)
+    assert model.dx == 1 and isinstance(model.input_obj.input_model, ca.GP_RBF)
+    model.fit()
+    mean = model.get_predicted_mean(xs, ca.IndexSetUniform(ns, res, 2))
+    # oracle: same pipeline on the CPU
+    xn, _, mu, sd = oracle.normalize_inputs(x)
+    z = np.linspace(xn.min(), xn.max(), n)[:, None]
+    warp = oracle.gp_rbf_optimize(xn, z)
+    np.testing.assert_allclose(model.input_obj.x, z)
+    zs = oracle.gp_rbf_predict(warp, (xs - mu) / sd)
+    np.testing.assert_allclose(model.input_obj.warp((xs - mu) / sd), zs, rtol=1e-3, atol=1e-3)
+    specs = [oracle.DenseLayerSpec(1.0, 1.0, None), oracle.DenseLayerSpec(0.5, 1.0, None)]
+    omodel, _ = oracle.mrgp_fit(z, y, oracle.index_bounds_uniform(n, res, 2), specs)
+    omean, _ = oracle.mrgp_predict(z, omodel, specs, model.input_obj.warp((xs - mu) / sd),
+                                   oracle.index_bounds_uniform(ns, res, 2), want_var=False)
+    assert _relerr(mean, omean) < 1e-6
