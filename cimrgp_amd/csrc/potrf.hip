@@ -246,8 +246,12 @@ static __device__ __forceinline__ void lds_barrier()
 // formula (for j < i < k it touches a not-yet-born Mi slot, which is reset at pivot i).
 // Waves left of the pivot column have nothing to do; register indices are compile-time
 // constants (u0 unrolled, wave index looped).
+constexpr int DG_NW = 8;              // waves of the diagonal kernel: two per SIMD (the loop is VALU-issue bound)
+constexpr int DG_NS = SB / DG_NW;     // register slots (columns) per lane
+constexpr int DG_NT = 64 * DG_NW;
+
 template <typename T>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(DG_NT)
 void k_diag64(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow, int kprev,
               T* __restrict__ inv, int32_t* info, int col_base)
 {
@@ -257,7 +261,8 @@ void k_diag64(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow, 
     constexpr int LS = SB + 1;
     __shared__ __attribute__((aligned(16))) unsigned char chunk[TL::BYTES];   // Lrow chunk, later L^-1 out
     __shared__ T S[SB * LS];                                                  // Schur block, later L out
-    __shared__ __attribute__((aligned(16))) T comb4[2][SB][4];                // four pivot-time columns of A
+    constexpr int BC = 4;                                                     // pivots per barrier
+    __shared__ __attribute__((aligned(16))) T comb4[2][SB][BC];               // BC pivot-time columns of A
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = tid & 63;
     const int g = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave id: provably uniform
@@ -265,7 +270,7 @@ void k_diag64(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow, 
     __builtin_amdgcn_s_setprio(3);
 
     STAMP(0);
-    for (int e = tid; e < SB * SB; e += 256) {
+    for (int e = tid; e < SB * SB; e += DG_NT) {
         const int r = e >> 6, c = e & 63;
         T v = (r == c) ? (T)1 : (T)0;
         if (r < w && c <= r) v = D[(int64_t)r * ld + c];
@@ -278,42 +283,43 @@ void k_diag64(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow, 
         for (int ct = 0; ct < 4; ++ct) acc[ct] = acc_zero<T>();
         for (int kc = 0; kc < kprev; kc += SB) {
             __syncthreads();
-            load_tile64<T>(chunk, Lrow + kc, ld, w, min(SB, kprev - kc));
+            if (tid < 256) load_tile64<T>(chunk, Lrow + kc, ld, w, min(SB, kprev - kc));
             __syncthreads();
-            mma_chunk64<T, false>(acc, chunk, chunk, g, lane);
+            if (g < 4) mma_chunk64<T, false>(acc, chunk, chunk, g, lane);
         }
+        if (g < 4) {
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+            for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = g * 16 + X::crow(lane, r), col = ct * 16 + (lane & 15);
-                if (row < w && col <= row) S[row * LS + col] -= acc[ct][r];
-            }
+                for (int r = 0; r < 4; ++r) {
+                    const int row = g * 16 + X::crow(lane, r), col = ct * 16 + (lane & 15);
+                    if (row < w && col <= row) S[row * LS + col] -= acc[ct][r];
+                }
+        }
     }
     __syncthreads();
 
-    T a[16];
+    T a[DG_NS];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) a[u] = S[i * LS + 16 * g + u];   // strict upper part of S is zero
+    for (int u = 0; u < DG_NS; ++u) a[u] = S[i * LS + DG_NS * g + u];   // strict upper part of S is zero
     T* lout = S;                                   // L[i][j]    at lout[i * LS + j]
     T* iout = reinterpret_cast<T*>(chunk);         // L^-1[j][c] at iout[j * SB + c]
     __syncthreads();
-    for (int e = tid; e < SB * SB; e += 256) iout[e] = (T)0;
+    for (int e = tid; e < SB * SB; e += DG_NT) iout[e] = (T)0;
     STAMP(2);
 
-    // Column loop, FOUR pivots per barrier.  The wave that owns columns j0..j0+3 (same register
-    // slots u0..u0+3 of every lane) eliminates them among themselves with wave-local broadcasts
-    // (v_readlane, no LDS, no barrier), publishes the four pivot-time columns with two 16-byte
-    // LDS stores per lane, and after ONE barrier every wave applies the rank-4 update to its
+    // Column loop, BC pivots per barrier.  The wave that owns columns j0..j0+BC-1 (same register
+    // slots u0..u0+BC-1 of every lane) eliminates them among themselves with wave-local broadcasts
+    // (v_readlane, no LDS, no barrier), publishes the BC pivot-time columns with 16-byte LDS
+    // stores, and after ONE barrier every wave applies the rank-BC update to its
     // slots right of the block.  A lane that is itself a pivot row of the block (i = j0 + p)
     // starts its not-yet-born inverse entries from 0 and takes contributions from pivots >= p only.
-    for (int gg = 0; gg < 4; ++gg) {
+    for (int gg = 0; gg < DG_NW; ++gg) {
 #pragma unroll
-        for (int ub = 0; ub < 4; ++ub) {
-            constexpr int BC = 4;
+        for (int ub = 0; ub < DG_NS / BC; ++ub) {
             const int u0 = BC * ub;
-            const int j0 = 16 * gg + u0;
-            T (*cb)[BC] = comb4[(j0 >> 2) & 1];
+            const int j0 = DG_NS * gg + u0;
+            T (*cb)[BC] = comb4[(j0 / BC) & 1];
             T colv[BC], rr[BC];
             if (g == gg) {
 #pragma unroll
@@ -355,9 +361,9 @@ void k_diag64(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow, 
                     nhr[t] = (in_block && i > j0 + t) ? (T)0 : -h * rr[t];
                 }
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
+                for (int u = 0; u < DG_NS; ++u) {
                     if (g > gg || u >= u0 + BC) {               // columns right of the block
-                        const int k = 16 * g + u;
+                        const int k = DG_NS * g + u;
                         T v = in_block ? (T)0 : a[u];
 #pragma unroll
                         for (int t = 0; t < BC; ++t) v = fma(nhr[t], cb[k][t], v);
@@ -369,7 +375,7 @@ void k_diag64(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow, 
     }
     STAMP(3);
     __syncthreads();
-    for (int e = tid; e < SB * SB; e += 256) {
+    for (int e = tid; e < SB * SB; e += DG_NT) {
         const int r = e >> 6, c = e & 63;
         if (r < w && c <= r) D[(int64_t)r * ld + c] = lout[r * LS + c];
         inv[e] = (r < w && c < w) ? iout[e] : (T)0;
@@ -550,7 +556,7 @@ static int panel_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info,
             T* inv = ws + (c0 / SB) * (SB * SB);
             const T* lrow = kmat + c0 * ld + k0;   // rows of the diagonal block, earlier panel columns
             if (FACTOR) {
-                hipLaunchKernelGGL((k_diag64<T>), dim3(1), dim3(256), 0, st,
+                hipLaunchKernelGGL((k_diag64<T>), dim3(1), dim3(DG_NT), 0, st,
                                    kmat + c0 * ld + c0, ld, sw, lrow, kprev, inv, info, (int)c0);
                 CIMRGP_LAUNCH_CHECK(fn);
             }
@@ -632,7 +638,7 @@ int factor_panel(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, int64_t k
         const int64_t pc = c0 + sw;
         T* inv = ws + (c0 / SB) * (SB * SB);
         const T* lrow = kmat + c0 * ld + k0;
-        hipLaunchKernelGGL((k_diag64<T>), dim3(1), dim3(256), 0, st,
+        hipLaunchKernelGGL((k_diag64<T>), dim3(1), dim3(DG_NT), 0, st,
                            kmat + c0 * ld + c0, ld, sw, lrow, kprev, inv, info, (int)c0);
         CIMRGP_LAUNCH_CHECK(fn);
         const int64_t m1 = n - pc;

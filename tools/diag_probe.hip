@@ -29,7 +29,7 @@ int main()
     long long st[32];
     for (int kprev = 0; kprev <= 192; kprev += 64) {
         for (int rep = 0; rep < 2; ++rep) {
-            hipLaunchKernelGGL((k_diag64<double>), dim3(1), dim3(256), 0, 0, dK + (size_t)256 * ld + 256, (int64_t)ld, 64, dK + (size_t)256 * ld + 256 - kprev, kprev, dws, dinfo, 0);
+            hipLaunchKernelGGL((k_diag64<double>), dim3(1), dim3(DG_NT), 0, 0, dK + (size_t)256 * ld + 256, (int64_t)ld, 64, dK + (size_t)256 * ld + 256 - kprev, kprev, dws, dinfo, 0);
             hipDeviceSynchronize();
             hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamp), sizeof(st));
             if (rep) printf("diag64 kprev=%3d: load %lld  mfma %lld  loop %lld  store %lld  total %lld ticks (%.1f us @2.35GHz)\n", kprev, st[1]-st[0], st[2]-st[1], st[3]-st[2], st[4]-st[3], st[4]-st[0], (st[4]-st[0])/2350.0);
@@ -40,7 +40,7 @@ int main()
         for (int rep = 0; rep < 2; ++rep) {
             hipEventRecord(e0);
             for (int it = 0; it < 64; ++it) {
-                hipLaunchKernelGGL((k_diag64<double>), dim3(1), dim3(256), 0, 0, dK + (size_t)256 * ld + 256, (int64_t)ld, 64, dK + (size_t)256 * ld + 256 - 128, 128, dws, dinfo, 0);
+                hipLaunchKernelGGL((k_diag64<double>), dim3(1), dim3(DG_NT), 0, 0, dK + (size_t)256 * ld + 256, (int64_t)ld, 64, dK + (size_t)256 * ld + 256 - 128, 128, dws, dinfo, 0);
                 hipLaunchKernelGGL((k_trsm64<double>), dim3(56), dim3(256), 0, 0, dK + (size_t)320 * ld + 256, (int64_t)ld, 1728, 56, (double*)nullptr, (int64_t)0, 0, 64, 128, dK + (size_t)256 * ld + 128, (int64_t)ld, dws);
             }
             hipEventRecord(e1); hipDeviceSynchronize();
@@ -49,7 +49,7 @@ int main()
         }
         hipEventRecord(e0);
         for (int it = 0; it < 64; ++it)
-            hipLaunchKernelGGL((k_diag64<double>), dim3(1), dim3(256), 0, 0, dK + (size_t)256 * ld + 256, (int64_t)ld, 64, dK + (size_t)256 * ld + 256, 0, dws, dinfo, 0);
+            hipLaunchKernelGGL((k_diag64<double>), dim3(1), dim3(DG_NT), 0, 0, dK + (size_t)256 * ld + 256, (int64_t)ld, 64, dK + (size_t)256 * ld + 256, 0, dws, dinfo, 0);
         hipEventRecord(e1); hipDeviceSynchronize();
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("64 x diag64 kprev=0 alone: %.1f us each\n", ms * 1e3 / 64);
