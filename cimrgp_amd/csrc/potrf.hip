@@ -281,10 +281,30 @@ void k_diag64(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow, 
         acc_t acc[4];
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc[ct] = acc_zero<T>();
+        // chunk kc+1 travels global -> registers while chunk kc is multiplied
+        constexpr int NR = SB * TL::CPR / DG_NT;      // 16-byte pieces per thread and chunk
+        uint4 regs[NR];
+#pragma unroll
+        for (int p = 0; p < NR; ++p) {
+            const int e = tid + DG_NT * p, r = e / TL::CPR, c = e - r * TL::CPR;
+            regs[p] = (r < w) ? *reinterpret_cast<const uint4*>(Lrow + (int64_t)r * ld + c * X::EPC) : make_uint4(0, 0, 0, 0);
+        }
         for (int kc = 0; kc < kprev; kc += SB) {
             __syncthreads();
-            if (tid < 256) load_tile64<T>(chunk, Lrow + kc, ld, w, min(SB, kprev - kc));
+#pragma unroll
+            for (int p = 0; p < NR; ++p) {
+                const int e = tid + DG_NT * p, r = e / TL::CPR, c = e - r * TL::CPR;
+                *reinterpret_cast<uint4*>(chunk + r * TL::LROW + c * 16) = regs[p];
+            }
             __syncthreads();
+            if (kc + SB < kprev) {
+#pragma unroll
+                for (int p = 0; p < NR; ++p) {
+                    const int e = tid + DG_NT * p, r = e / TL::CPR, c = e - r * TL::CPR;
+                    regs[p] = (r < w) ? *reinterpret_cast<const uint4*>(Lrow + kc + SB + (int64_t)r * ld + c * X::EPC)
+                                      : make_uint4(0, 0, 0, 0);
+                }
+            }
             if (g < 4) mma_chunk64<T, false>(acc, chunk, chunk, g, lane);
         }
         if (g < 4) {
