@@ -70,6 +70,7 @@ static TrailRec* rec_open(hipStream_t st, double flops)
 namespace {
 
 constexpr int SB = 64;   // diagonal sub-block
+constexpr int64_t ROWS_START_BELOW = 4608;   // carried rows start once the trailing matrix is smaller than this
 
 
 template <typename T> struct Tile64 {
@@ -623,6 +624,7 @@ static int panel_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info,
 namespace {
 struct LookAhead {
     hipStream_t side = nullptr;        // panel chain (high priority)
+    hipStream_t rows = nullptr;        // carried rows: lags behind the factorisation, lowest priority
     std::vector<hipEvent_t> ev;
     int device = -1;
 };
@@ -637,6 +639,7 @@ LookAhead* lookahead_ctx(size_t nevents)
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         if (hipStreamCreateWithPriority(&la.side, hipStreamNonBlocking, hi) != hipSuccess) { la.side = nullptr; return nullptr; }
+        if (hipStreamCreateWithPriority(&la.rows, hipStreamNonBlocking, lo) != hipSuccess) la.rows = nullptr;
         la.device = dev;
     }
     while (la.ev.size() < nevents) {
@@ -700,7 +703,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     const bool rows = (b != nullptr && m > 0);
     CIMRGP_HIP_TRY(hipMemsetAsync(info, 0, sizeof(int32_t), st), "hipMemsetAsync(info)");
     const int64_t npanels = (n + CIMRGP_NB - 1) / CIMRGP_NB;
-    LookAhead* la = (npanels > 2) ? lookahead_ctx((size_t)(2 * npanels + 2)) : nullptr;
+    LookAhead* la = (npanels > 2) ? lookahead_ctx((size_t)(3 * npanels + 4)) : nullptr;
     if (la == nullptr) {
         int rc0 = panel_sweep<T, true>(k, n, ld, ws, info, b, m, ldb, st);
         return rc0 ? rc0 : build_invT<T>(k, n, ld, ws, st);
@@ -716,12 +719,18 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     if (rc) return rc;
     bool side_pending = false;
     hipEvent_t ev_panel = nullptr;
+    int64_t rows_next = 0;                             // first panel the carried rows have not seen yet
     for (int64_t k0 = 0; k0 < n; k0 += CIMRGP_NB) {
         const int64_t w  = (n - k0 < CIMRGP_NB) ? (n - k0) : CIMRGP_NB;
         const int64_t k1 = k0 + w;
         if (side_pending) {                            // panel k0 was factored on the side stream
             CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0), "hipStreamWaitEvent");
             side_pending = false;
+        }
+        hipEvent_t ev_final = nullptr;                 // "panel k0 is final", for the carried rows' queue
+        if (rows && la->rows) {
+            ev_final = la->ev[ne++];
+            CIMRGP_HIP_TRY(hipEventRecord(ev_final, st), "hipEventRecord");
         }
         if (k1 < n) {
             const int64_t wn = (n - k1 < CIMRGP_NB) ? (n - k1) : CIMRGP_NB;   // next panel
@@ -749,16 +758,37 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
                 if (rc) return rc;
             }
         }
-        if (rows) {                                    // panel k0 is final: solve + update the carried rows
-            hipLaunchKernelGGL((k_trsm256<T>), dim3((unsigned)((m + TR - 1) / TR)), dim3(256), 0, st,
-                               b + k0, ldb, (int)m, (int)w, (const T*)(k + k0 * ld + k0), ld,
-                               (const T*)(ws + (k0 / SB) * (SB * SB)));
-            CIMRGP_LAUNCH_CHECK("cimrgp_potrf_rows");
-            if (n > k1) {
-                rc = gemm_nt_sub<T>(b + k1, ldb, b + k0, ldb, k + k1 * ld + k0, ld, m, n - k1, (int)w, false, st);
-                if (rc) return rc;
+        if (rows) {
+            // Panel k0 is final: solve + update the carried rows.  They form their own chain (panel
+            // p+1 of the rows needs panel p of the rows) that depends on the factorisation only
+            // through "panel k0 final", so it runs on a third queue and lags behind: nothing of it
+            // is issued while the trailing updates are still large (that phase is MFMA-bound and
+            // the rows would only take compute units away from the critical path); from then on it
+            // fills the compute units the latency-bound panel chain leaves idle.
+            hipStream_t sq = la->rows ? la->rows : st;
+            const bool defer = (sq != st) && (n - k1 > ROWS_START_BELOW) && (k1 < n);
+            if (!defer) {
+                if (sq != st) CIMRGP_HIP_TRY(hipStreamWaitEvent(sq, ev_final, 0), "hipStreamWaitEvent");
+                for (int64_t r0 = rows_next; r0 <= k0; r0 += CIMRGP_NB) {
+                    const int64_t rw = (n - r0 < CIMRGP_NB) ? (n - r0) : CIMRGP_NB;
+                    const int64_t r1 = r0 + rw;
+                    hipLaunchKernelGGL((k_trsm256<T>), dim3((unsigned)((m + TR - 1) / TR)), dim3(256), 0, sq,
+                                       b + r0, ldb, (int)m, (int)rw, (const T*)(k + r0 * ld + r0), ld,
+                                       (const T*)(ws + (r0 / SB) * (SB * SB)));
+                    CIMRGP_LAUNCH_CHECK("cimrgp_potrf_rows");
+                    if (n > r1) {
+                        rc = gemm_nt_sub<T>(b + r1, ldb, b + r0, ldb, k + r1 * ld + r0, ld, m, n - r1, (int)rw, false, sq);
+                        if (rc) return rc;
+                    }
+                }
+                rows_next = k1;
             }
         }
+    }
+    if (rows && la->rows) {
+        hipEvent_t ev_rows_done = la->ev[ne++];
+        CIMRGP_HIP_TRY(hipEventRecord(ev_rows_done, la->rows), "hipEventRecord");
+        CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_rows_done, 0), "hipStreamWaitEvent");
     }
     if (side_pending) CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0), "hipStreamWaitEvent");
     return build_invT<T>(k, n, ld, ws, st);
