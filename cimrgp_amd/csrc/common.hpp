@@ -131,4 +131,11 @@ template <typename T> int misc_logdet_half(const T* l, int64_t n, int64_t ld, do
 template <typename T> int lml_grad_run(const T* x, int64_t n, int d, const T* kinv, int64_t ld, const T* alpha, int q,
                                        double ell, double sf2, double noise, double* out3, double* scratch, hipStream_t st);
 
+// reduced.hip
+template <typename T> int laplace_basis_run(const T* x, int64_t n, int d, const double* interval, int m, T* phi, hipStream_t st);
+template <typename T> int basis_moments_run(const T* phi, const T* y, const T* fbar, const T* fvar, const double* eau, int64_t n,
+                                            int m, int q, double* out, double* scratch, hipStream_t st);
+template <typename T> int basis_apply_run(const T* phi, int64_t n, int m, const double* eau, int q, const double* bias,
+                                          const double* c2, double bias_var, T* mean, T* var, int accumulate, hipStream_t st);
+
 }  // namespace cimrgp
