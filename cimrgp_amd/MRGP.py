@@ -56,6 +56,17 @@ class DenseStats(object):
 
 
 class MultiResolutionGaussianProcess(object):
+    def __new__(cls, *args, **kwargs):
+        """A basis-function object selects the reference's own reduced-rank blocks
+        (``ReducedRank.ReducedRankMRGP``); without one the blocks are
+        exact RBF GPs (this class)."""
+        if cls is MultiResolutionGaussianProcess:
+            basis = kwargs.get('basis_function_obj', args[3] if len(args) > 3 else None)
+            if basis is not None:
+                from .ReducedRank import ReducedRankMRGP
+                return object.__new__(ReducedRankMRGP)
+        return object.__new__(cls)
+
     def __init__(self, train_xy,
                  n_basis=None,
                  index_set_obj=None,
@@ -116,8 +127,8 @@ class MultiResolutionGaussianProcess(object):
             self.spectral_density_obj = [spectral_density_obj] * self.n_layers
         for k in self.spectral_density_obj:
             if not isinstance(k, RBFKernel):
-                # reduced-rank (Laplacian basis + Matern spectral density) blocks: SURVEY 8f rank 2
-                raise TypeError('not yet supported')
+                # a spectral density without a basis-function object: neither path applies
+                raise TypeError('spectral_density_obj must be an RBFKernel when basis_function_obj is None')
         if snr_ratio is not None:
             # reference: initial noise variance of layer 0 from an SNR (MRGP.py:196-199,966-971)
             self.spectral_density_obj = list(self.spectral_density_obj)

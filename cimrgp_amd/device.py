@@ -248,3 +248,70 @@ def lml_grad(x, kinv, n, alpha, ell, sf2, noise):
                                    alpha.shape[1], float(ell), float(sf2), float(noise), _p(out), _p(scratch), _stream()),
                "cimrgp_lml_grad")
     return out
+
+
+# ---- reduced-rank (Laplacian basis) block path ------------------------------------------------
+def _f64dev(a, device):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(device)
+
+
+def laplace_basis(x, interval, n_basis, out=None):
+    """Phi (n x m) of the Dirichlet-Laplacian eigenfunctions on [-L, L]^d for device points x."""
+    n, d = x.shape
+    if out is None:
+        out = torch.empty((n, int(n_basis)), dtype=x.dtype, device=x.device)
+    lib = _lib.load()
+    iv = _f64dev(np.asarray(interval, dtype=np.float64).reshape(-1), x.device)
+    if iv.numel() != d:
+        raise ValueError('Basis interval should have the same dimensionality as the input.')
+    _lib.check(lib.cimrgp_laplace_basis(_DT[x.dtype], _p(x), n, d, _p(iv), int(n_basis), _p(out), _stream()),
+               "cimrgp_laplace_basis")
+    return out
+
+
+class BlockMoments(object):
+    """Host copy of the sums one block's updates need (see include/cimrgp.h, cimrgp_basis_moments)."""
+    __slots__ = ("proj", "colsum", "colsum2", "resid_sum", "resid_sq", "fvar_sum", "n")
+
+    def __init__(self, rec, m, q, n):
+        self.proj = rec[:m * q].reshape(m, q)           # Phi^T r0
+        self.colsum = rec[m * q:m * q + m]
+        self.colsum2 = rec[m * q + m:m * q + 2 * m]
+        self.resid_sum = rec[m * q + 2 * m:m * q + 2 * m + q]
+        self.resid_sq = float(rec[m * q + 2 * m + q])
+        self.fvar_sum = float(rec[m * q + 2 * m + q + 1])
+        self.n = int(n)
+
+
+def basis_moments(phi, y, fbar, fvar, eau):
+    """One pass over Phi: every N-dependent sum of the block's variational updates, with
+    r0 = y - fbar - Phi E[au]^T.  ``eau``: (q x m) host array.  Returns BlockMoments (host)."""
+    n, m = phi.shape
+    q = y.shape[1]
+    lib = _lib.load()
+    rec_len = m * q + 2 * m + q + 2
+    out = torch.empty(rec_len, dtype=torch.float64, device=phi.device)
+    scratch = torch.empty(max(lib.cimrgp_basis_moments_scratch_bytes(n, m, q), 8) // 8, dtype=torch.float64,
+                          device=phi.device)
+    e = _f64dev(eau, phi.device)
+    for t in (y, fbar, fvar):
+        if t is not None and not t.is_contiguous():
+            raise ValueError("basis_moments needs contiguous operands")
+    _lib.check(lib.cimrgp_basis_moments(_DT[phi.dtype], _p(phi), _p(y), _p(fbar), _p(fvar), _p(e), n, m, q, _p(out),
+                                        _p(scratch), _stream()), "cimrgp_basis_moments")
+    return BlockMoments(out.cpu().numpy(), m, q, n)
+
+
+def basis_apply(phi, eau, bias=None, c2=None, bias_var=0.0, mean=None, var=None, accumulate=False):
+    """mean (+)= bias + Phi E[au]^T ;  var (+)= bias_var + Phi^2 c2."""
+    n, m = phi.shape
+    q = np.asarray(eau).shape[0]
+    lib = _lib.load()
+    e = _f64dev(eau, phi.device)
+    b = None if bias is None else _f64dev(bias, phi.device)
+    c = None if c2 is None else _f64dev(c2, phi.device)
+    for t in (mean, var):
+        if t is not None and not t.is_contiguous():
+            raise ValueError("basis_apply needs contiguous outputs")
+    _lib.check(lib.cimrgp_basis_apply(_DT[phi.dtype], _p(phi), n, m, _p(e), q, _p(b), _p(c), float(bias_var), _p(mean),
+                                      _p(var), int(bool(accumulate)), _stream()), "cimrgp_basis_apply")

@@ -177,7 +177,7 @@ class _Block:
     """State of one (layer, region) block: everything the reference spreads over its
     Prior / Posterior / Stats objects for that region."""
 
-    def __init__(self, x, y_rows, n_basis, dy, spectral, prior_influence, factor):
+    def __init__(self, x, y_rows, n_basis, dy, spectral, prior_influence, factor, noise_var=1.0):
         self.x = x
         self.rows = y_rows
         self.interval = basis_interval(x, factor)
@@ -189,7 +189,7 @@ class _Block:
         self.ard_shape0 = TINY * np.ones(n_basis)
         self.ard_scale0 = self.ard_shape0 / prior_influence
         self.noise_shape0 = TINY
-        self.noise_scale0 = (TINY + 1.0) * 1.0
+        self.noise_scale0 = (TINY + 1.0) * noise_var                   # Priors.py:262-267
         self.bias_prec0 = TINY
         self.ard_mean = self.ard_shape0 / self.ard_scale0
         self.ard_log_mean = psi(self.ard_shape0) - np.log(self.ard_scale0)
@@ -239,7 +239,7 @@ class ReducedRankModel:
     priors, no input warping)."""
 
     def __init__(self, x, y, bounds, n_basis, nu=1.0, ell=1.0, sf=1.0, forced_independence=True,
-                 interval_factor=1.0):
+                 interval_factor=1.0, snr_ratio=None):
         x = np.asarray(x, dtype=np.float64)
         self.y = np.asarray(y, dtype=np.float64)
         self.mean_x = np.mean(x, 0)
@@ -252,8 +252,13 @@ class ReducedRankModel:
         self.fi = forced_independence
         self.n_layers = len(bounds)
         spectral = lambda s: matern_spectral(s, nu, ell, sf)
-        self.blocks = [[_Block(self.xn[a:b], slice(int(a), int(b)), n_basis, self.dy, spectral, sf, interval_factor)
-                        for a, b in layer] for layer in bounds]
+        noise_var0 = 1.0
+        if snr_ratio is not None:                                      # MRGP.py:966-971, layer 0 only (:196-203)
+            n0 = self.y.shape[0]
+            noise_var0 = (np.linalg.norm(self.y) ** 2 / n0 - np.dot(self.y.mean(0), self.y.mean(0))) / snr_ratio
+        self.blocks = [[_Block(self.xn[a:b], slice(int(a), int(b)), n_basis, self.dy, spectral, sf, interval_factor,
+                               noise_var0 if j == 0 else 1.0)
+                        for a, b in layer] for j, layer in enumerate(bounds)]
         zero_bing = bingham_from_matrix(np.zeros((self.dy, self.dy)))
         if self.fi:
             for layer in self.blocks:

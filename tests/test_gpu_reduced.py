@@ -1,0 +1,218 @@
+"""GPU parity of the reduced-rank block path: the three HIP kernels
+against NumPy, and the full fiMRGP / ciMRGP fits against (a) the reference's own fitted models
+(tests/golden/reference_model_*.npz) and (b) the pinned oracle on other seeded inputs."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import index_bounds_uniform
+from oracle.reduced import ReducedRankModel, laplace_basis
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+TOL_F64 = 1e-9          # f64 kernels vs NumPy: summation order only
+TOL_F32 = 2e-4
+
+
+@pytest.fixture(scope="module")
+def ca():
+    import cimrgp_amd
+    cimrgp_amd.device.require_gpu()
+    return cimrgp_amd
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - b)) / (np.max(np.abs(b)) + 1e-300))
+
+
+@pytest.mark.parametrize("n,d,m", [(1, 1, 1), (257, 1, 30), (1000, 2, 64), (4099, 3, 17)])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_laplace_basis_kernel(ca, n, d, m, dtype):
+    rng = np.random.default_rng(n + d)
+    x = rng.uniform(-1.5, 1.5, size=(n, d))
+    interval = 1.1 * np.max(np.abs(x), axis=0) + 0.05
+    td = ca.device.as_torch_dtype(dtype)
+    xd = torch.as_tensor(x).to("cuda", td)
+    phi = ca.device.laplace_basis(xd, interval, m).double().cpu().numpy()
+    ref, _ = laplace_basis(xd.double().cpu().numpy(), interval, m)
+    assert phi.shape == (n, m)
+    assert np.max(np.abs(phi - ref)) < (1e-12 if dtype == "f64" else 2e-5) * max(1.0, m)
+
+
+@pytest.mark.parametrize("n,m,q,latent", [(1, 1, 2, False), (255, 30, 2, True), (257, 64, 8, True), (5000, 40, 3, True),
+                                           (70001, 30, 2, False)])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_basis_moments_kernel(ca, n, m, q, latent, dtype):
+    rng = np.random.default_rng(n * 7 + m)
+    td = ca.device.as_torch_dtype(dtype)
+    phi = torch.as_tensor(rng.normal(size=(n, m))).to("cuda", td)
+    y = torch.as_tensor(rng.normal(size=(n, q)) + 3.0).to("cuda", td)
+    fbar = torch.as_tensor(rng.normal(size=(n, q))).to("cuda", td) if latent else None
+    fvar = torch.as_tensor(rng.uniform(0, 1, size=n)).to("cuda", td) if latent else None
+    eau = rng.normal(size=(q, m)) * 0.1
+    mom = ca.device.basis_moments(phi, y, fbar, fvar, eau)
+    p = phi.double().cpu().numpy()
+    r0 = y.double().cpu().numpy() - (fbar.double().cpu().numpy() if latent else 0.0) - p @ eau.T
+    tol = TOL_F64 if dtype == "f64" else TOL_F32
+    scale = float(np.sqrt(n))
+    assert np.max(np.abs(mom.proj - p.T @ r0)) < tol * scale * 10
+    assert np.max(np.abs(mom.colsum - p.sum(0))) < tol * scale * 10
+    assert _rel(mom.colsum2, (p * p).sum(0)) < tol
+    assert np.max(np.abs(mom.resid_sum - r0.sum(0))) < tol * n
+    assert abs(mom.resid_sq - np.sum(r0 * r0)) < tol * np.sum(r0 * r0)
+    assert abs(mom.fvar_sum - (fvar.double().sum().item() if latent else 0.0)) < tol * n
+    assert mom.n == n
+    # fixed-order reduction: bit-identical on repetition
+    again = ca.device.basis_moments(phi, y, fbar, fvar, eau)
+    assert np.array_equal(again.proj, mom.proj) and again.resid_sq == mom.resid_sq
+
+
+@pytest.mark.parametrize("n,m,q", [(1, 1, 2), (300, 30, 2), (4097, 64, 8)])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_basis_apply_kernel(ca, n, m, q, dtype):
+    rng = np.random.default_rng(n + m + q)
+    td = ca.device.as_torch_dtype(dtype)
+    phi = torch.as_tensor(rng.normal(size=(n, m))).to("cuda", td)
+    eau, bias, c2 = rng.normal(size=(q, m)), rng.normal(size=q), rng.uniform(0, 1, size=m)
+    p = phi.double().cpu().numpy()
+    want_mean = bias + p @ eau.T
+    want_var = 0.25 + (p * p) @ c2
+    mean = torch.full((n, q), 7.0, dtype=td, device="cuda")
+    var = torch.full((n,), 7.0, dtype=td, device="cuda")
+    ca.device.basis_apply(phi, eau, bias, c2, 0.25, mean=mean, var=var, accumulate=False)
+    tol = 1e-12 if dtype == "f64" else 1e-5
+    assert np.max(np.abs(mean.double().cpu().numpy() - want_mean)) < tol * m
+    assert np.max(np.abs(var.double().cpu().numpy() - want_var)) < tol * m
+    ca.device.basis_apply(phi, eau, bias, c2, 0.25, mean=mean, var=var, accumulate=True)
+    assert np.max(np.abs(mean.double().cpu().numpy() - 2 * want_mean)) < 2 * tol * m
+    assert np.max(np.abs(var.double().cpu().numpy() - 2 * want_var)) < 2 * tol * m
+    only_mean = torch.zeros((n, q), dtype=td, device="cuda")
+    ca.device.basis_apply(phi, eau, None, None, 0.0, mean=only_mean)
+    assert np.max(np.abs(only_mean.double().cpu().numpy() - p @ eau.T)) < tol * m
+
+
+def test_kernel_argument_errors(ca):
+    x = torch.zeros((4, 1), dtype=torch.float64, device="cuda")
+    with pytest.raises(RuntimeError):
+        ca.device.laplace_basis(x, [1.0], 65)
+    with pytest.raises(ValueError):
+        ca.device.laplace_basis(x, [1.0, 2.0], 5)
+
+
+def _build(ca, x, y, res, n_basis, forced, **kw):
+    return ca.MultiResolutionGaussianProcess(train_xy=[x, y], n_basis=n_basis,
+                                             index_set_obj=ca.IndexSetUniform(x.shape[0], res, 2),
+                                             basis_function_obj=ca.LaplacianEigenpairs(),
+                                             spectral_density_obj=kw.pop("spectral", ca.MaternKernel(nu=1, l=1, sf=1)),
+                                             adaptive_inputs=False, forced_independence=forced, **kw)
+
+
+@pytest.mark.parametrize("tag", ["fi_r2", "fi_r3", "ci_r2"])
+def test_model_matches_reference_fit(ca, golden_dir, tag):
+    """The whole sweep on the GPU against the reference's own fitted model (5 iterations)."""
+    z = np.load(os.path.join(golden_dir, "reference_model_%s.npz" % tag))
+    res = int(z["resolution"])
+    model = _build(ca, z["x"], z["y"], res, int(z["n_basis"]), bool(z["forced_independence"]))
+    model.fit(5, None)
+    tol = 1e-8
+    for j in range(model.n_layers):
+        f_mean, f_var = model.latent_functions(j)
+        st = model.stats_obj[j]
+        for l in range(model.n_regions[j]):
+            key = "_%d_%d" % (j, l)
+            assert _rel(st.scale_axis_mean[l], z["scale_axis_mean" + key]) < tol
+            assert _rel(st.bias_mean[l], z["bias_mean" + key]) < tol
+            assert _rel(f_mean[l], z["latent_f_mean" + key]) < tol
+            assert _rel(f_var[l], z["latent_f_var" + key]) < tol
+    idx_t = ca.IndexSetUniform(z["xt"].shape[0], res, 2)
+    assert _rel(model.get_predicted_mean(z["xt"]), z["pred_mean_global"]) < tol
+    assert _rel(model.get_central_moment2(z["xt"]), z["pred_var_global"]) < tol
+    assert _rel(model.get_predicted_mean(z["xt"], idx_t), z["pred_mean_index"]) < tol
+    assert _rel(model.get_central_moment2(z["xt"], idx_t), z["pred_var_index"]) < tol
+
+
+@pytest.mark.parametrize("forced", [True, False])
+def test_model_matches_oracle_2d_inputs(ca, forced):
+    """Other shapes than the goldens: 2-D inputs, 3 outputs, ragged blocks, widened intervals,
+    SNR-initialised noise; against the (pinned) oracle."""
+    rng = np.random.default_rng(5)
+    n, ns, res, m = 1003, 301, 2, 12
+    x = rng.uniform(-1, 1, size=(n, 2))
+    x = x[np.argsort(x[:, 0])]
+    y = np.stack([np.sin(3 * x[:, 0]) + x[:, 1], np.cos(2 * x[:, 1]) * x[:, 0], x[:, 0] ** 2], axis=1) \
+        + 0.05 * rng.normal(size=(n, 3))
+    xs = rng.uniform(-1, 1, size=(ns, 2))
+    xs = xs[np.argsort(xs[:, 0])]
+    spectral = ca.MaternKernel(nu=1.5, l=0.8, sf=1.3)
+    model = _build(ca, x, y, res, m, forced, spectral=spectral, interval_factor=1.2, snr_ratio=10.0)
+    model.fit(4, None)
+    omodel = ReducedRankModel(x, y, index_bounds_uniform(n, res, 2), m, nu=1.5, ell=0.8, sf=1.3,
+                              forced_independence=forced, interval_factor=1.2, snr_ratio=10.0)
+    omodel.fit(4)
+    tb = index_bounds_uniform(ns, res, 2)
+    idx_t = ca.IndexSetUniform(ns, res, 2)
+    tol = 1e-7
+    for j in range(res + 1):
+        for l in range(model.n_regions[j]):
+            assert _rel(model.stats_obj[j].scale_axis_mean[l], omodel.blocks[j][l].eau) < tol
+            assert abs(model.stats_obj[j].noise_mean[l] - omodel.blocks[j][l].noise_mean) < tol * omodel.blocks[j][l].noise_mean
+    assert _rel(model.get_predicted_mean(xs, idx_t), omodel.predict_mean(xs, tb)) < tol
+    assert _rel(model.get_central_moment2(xs, idx_t), omodel.predict_var(xs, tb)) < tol
+    assert _rel(model.get_predicted_mean(xs), omodel.predict_mean(xs)) < tol
+    ll = model.get_test_likelihood([xs, np.zeros((ns, 3))], idx_t)
+    assert np.isfinite(ll)
+
+
+def test_model_f32_close_to_f64(ca, golden_dir):
+    z = np.load(os.path.join(golden_dir, "reference_model_fi_r2.npz"))
+    model = _build(ca, z["x"], z["y"], 2, int(z["n_basis"]), True, dtype="f32")
+    model.fit(5, None)
+    idx_t = ca.IndexSetUniform(z["xt"].shape[0], 2, 2)
+    assert _rel(model.get_predicted_mean(z["xt"], idx_t), z["pred_mean_index"]) < 5e-3
+
+
+def _two_rank_worker(rank, world, port, out_dir, forced):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as td
+    import cimrgp_amd as ca
+    torch.cuda.set_device(0)
+    td.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                             "reference_model_%s.npz" % ("fi_r3" if forced else "ci_r2")))
+    res = int(z["resolution"])
+    model = _build(ca, z["x"], z["y"], res, int(z["n_basis"]), forced)
+    model.fit(5, None)
+    idx_t = ca.IndexSetUniform(z["xt"].shape[0], res, 2)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), mean=model.get_predicted_mean(z["xt"], idx_t),
+             var=model.get_central_moment2(z["xt"], idx_t), glob=model.get_predicted_mean(z["xt"]),
+             eau_last=model.stats_obj[res].scale_axis_mean[model.n_regions[res] - 1])
+    td.destroy_process_group()
+
+
+@pytest.mark.parametrize("forced", [True, False])
+def test_two_rank_sharded_reduced_model(ca, golden_dir, tmp_path, forced):
+    """Blocks sharded over 2 ranks (sharing the box's one GPU, gloo carrying the device tensors):
+    per-layer latent-function reduce, shared-axis evidence reduce (ciMRGP), prediction reduce;
+    both ranks must reproduce the reference's single-process fit."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), forced), nprocs=2, join=True)
+    tag = "fi_r3" if forced else "ci_r2"
+    z = np.load(os.path.join(golden_dir, "reference_model_%s.npz" % tag))
+    res = int(z["resolution"])
+    last = "scale_axis_mean_%d_%d" % (res, 2 ** res - 1)
+    for rank in range(2):
+        g = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
+        assert _rel(g["mean"], z["pred_mean_index"]) < 1e-8
+        assert _rel(g["var"], z["pred_var_index"]) < 1e-8
+        assert _rel(g["glob"], z["pred_mean_global"]) < 1e-8
+        assert _rel(g["eau_last"], z[last]) < 1e-8           # host statistics synchronised to every rank
