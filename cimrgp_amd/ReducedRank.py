@@ -5,12 +5,13 @@ Every block (layer j, region l) expands its targets in ``n_basis`` Laplacian eig
 (KernelClass.py:9-37) weighted by a Matern spectral prior and runs the mean-field sweep of
 MRGP.py:574-731.  What scales with the number of samples is only ever
 
-  * building Phi (n x m),
   * the sums  Phi^T r, colsum Phi, colsum Phi^2, sum r, sum |r|^2, sum f_var  over a block,
   * applying  bias + Phi E[au]^T  and  bias_var + Phi^2 c2  to n points,
 
-and those three are HIP kernels (csrc/reduced.hip) behind ``cimrgp_laplace_basis``,
-``cimrgp_basis_moments`` and ``cimrgp_basis_apply``.  The factor updates themselves touch
+and those are HIP kernels (csrc/reduced.hip) behind ``cimrgp_basis_moments`` and
+``cimrgp_basis_apply``.  Neither reads Phi from memory: a row of it is regenerated in registers
+from x by a sine recurrence, so a sweep streams only x, y and the latent function.
+``cimrgp_laplace_basis`` materialises Phi for callers that want ``model.phi_x``.  The factor updates themselves touch
 m x q numbers per block and stay on the host, in the classes below, which keep the reference's
 names and attribute layout (lists over regions) so that code written against
 ``model.posterior_obj[j]`` / ``model.stats_obj[j]`` keeps working:
@@ -514,10 +515,10 @@ class ReducedRankMRGP(MultiResolutionGaussianProcess):
         self.owner = [dist.assign_blocks(self.n_samps[j], self.world_size) for j in range(self.n_layers)]
 
         # basis intervals, eigenvalues, prior spectral weights (MRGP.py:136-176,297-335) and Phi on the GPU
-        self.train_basis_intervals, self.lambda_, self.spectral_density_prior, self.phi_x = [], [], [], []
+        self.train_basis_intervals, self.lambda_, self.spectral_density_prior = [], [], []
         orders = np.arange(1, self.n_basis + 1, dtype=np.float64)
         for j in range(self.n_layers):
-            iv_j, lam_j, spec_j, phi_j = [], [], [], []
+            iv_j, lam_j, spec_j = [], [], []
             for l, (a, b) in enumerate(bounds[j]):
                 a, b = int(a), int(b)
                 interval = self.interval_factor[j] * np.max(np.abs(x_host[a:b]), axis=0)     # BasisInterval.py:15-16
@@ -529,12 +530,9 @@ class ReducedRankMRGP(MultiResolutionGaussianProcess):
                 iv_j.append(interval)
                 lam_j.append(lam)
                 spec_j.append(spec)
-                phi_j.append(dev.laplace_basis(self._x_dev[a:b], interval, self.n_basis)
-                             if self.owner[j][l] == self.rank else None)
             self.train_basis_intervals.append(iv_j)
             self.lambda_.append(lam_j)
             self.spectral_density_prior.append(spec_j)
-            self.phi_x.append(phi_j)
 
         sf = [1.0 if s is None else s.sf for s in self.spectral_density_obj]
         influence = float(np.mean(sf))
@@ -585,6 +583,13 @@ class ReducedRankMRGP(MultiResolutionGaussianProcess):
                 self._fit()
         self._fitted = True
 
+    @property
+    def phi_x(self):
+        """Phi per block (device tensors), materialised on demand -- the sweep itself never
+        stores it (the reference keeps ``phi_x[j][l]`` resident, MRGP.py:160-176)."""
+        return [[dev.laplace_basis(self._x_dev[int(a):int(b)], self.train_basis_intervals[j][l], self.n_basis)
+                 for l, (a, b) in enumerate(self.index_set_obj.bounds[j])] for j in range(self.n_layers)]
+
     def _block_views(self, j, l):
         a, b = (int(v) for v in self.index_set_obj.bounds[j][l])
         f, v = self._latent[j]
@@ -594,7 +599,8 @@ class ReducedRankMRGP(MultiResolutionGaussianProcess):
         out = {}
         for l in owned:
             a, b, fbar, fvar = self._block_views(j, l)
-            out[l] = dev.basis_moments(self.phi_x[j][l], targets[l], fbar, fvar, self.stats_obj[j].scale_axis_mean[l])
+            out[l] = dev.basis_moments(self._x_dev[a:b], self.train_basis_intervals[j][l], self.n_basis, targets[l], fbar,
+                                       fvar, self.stats_obj[j].scale_axis_mean[l])
         return out
 
     def _update_latent_functions(self, j, owned):
@@ -607,8 +613,9 @@ class ReducedRankMRGP(MultiResolutionGaussianProcess):
         st = self.stats_obj[j]
         for l in owned:
             a, b = (int(t) for t in self.index_set_obj.bounds[j][l])
-            dev.basis_apply(self.phi_x[j][l], st.scale_axis_mean[l], st.bias_mean[l], st.scale_axis_central_moment2[l],
-                            st.bias_var[l], mean=delta_f[a:b], var=delta_v[a:b], accumulate=False)
+            dev.basis_apply(self._x_dev[a:b], self.train_basis_intervals[j][l], self.n_basis, st.scale_axis_mean[l],
+                            st.bias_mean[l], st.scale_axis_central_moment2[l], st.bias_var[l], mean=delta_f[a:b],
+                            var=delta_v[a:b], accumulate=False)
         if self.world_size > 1:
             fused[:, :self.dy] = delta_f
             fused[:, self.dy] = delta_v
@@ -686,7 +693,8 @@ class ReducedRankMRGP(MultiResolutionGaussianProcess):
                     targets[l] = self._y[a:b]
                 else:
                     t = fbar.clone()
-                    dev.basis_apply(self.phi_x[j][l], st.scale_axis_mean[l], st.bias_mean[l], mean=t, accumulate=True)
+                    dev.basis_apply(self._x_dev[a:b], self.train_basis_intervals[j][l], self.n_basis, st.scale_axis_mean[l],
+                                    st.bias_mean[l], mean=t, accumulate=True)
                     targets[l] = t
             previous = self.shared_prior if j == 0 else self.shared_posterior.snapshot()
 
@@ -732,9 +740,8 @@ class ReducedRankMRGP(MultiResolutionGaussianProcess):
             # every prediction is taken from resolution 0 (MRGP.py:733-762, 832-860)
             if self.owner[0][0] == self.rank:
                 st = self.stats_obj[0]
-                phi = dev.laplace_basis(xs, self.train_basis_intervals[0][0], self.n_basis)
-                dev.basis_apply(phi, st.scale_axis_mean[0], st.bias_mean[0], st.scale_axis_central_moment2[0],
-                                st.bias_var[0], mean=mean, var=total, accumulate=False)
+                dev.basis_apply(xs, self.train_basis_intervals[0][0], self.n_basis, st.scale_axis_mean[0], st.bias_mean[0],
+                                st.scale_axis_central_moment2[0], st.bias_var[0], mean=mean, var=total, accumulate=False)
         else:
             n_layers = index_set.get_n_resolutions() + 1
             coarser = torch.zeros(ns, dtype=self.dtype, device=self.device) if want_var else None
@@ -743,9 +750,9 @@ class ReducedRankMRGP(MultiResolutionGaussianProcess):
                 own = torch.zeros(ns, dtype=self.dtype, device=self.device) if want_var else None
                 for l in self._owned(j):
                     a, b = (int(v) for v in index_set.bounds[j][l])
-                    phi = dev.laplace_basis(xs[a:b], self.train_basis_intervals[j][l], self.n_basis)
-                    dev.basis_apply(phi, st.scale_axis_mean[l], st.bias_mean[l], st.scale_axis_central_moment2[l],
-                                    st.bias_var[l], mean=mean[a:b], var=own[a:b] if want_var else None, accumulate=True)
+                    dev.basis_apply(xs[a:b], self.train_basis_intervals[j][l], self.n_basis, st.scale_axis_mean[l],
+                                    st.bias_mean[l], st.scale_axis_central_moment2[l], st.bias_var[l], mean=mean[a:b],
+                                    var=own[a:b] if want_var else None, accumulate=True)
                     if want_var:
                         # MRGP.py:905-937: own term + n_l / E[tau] + the coarser layers' variance at the
                         # region's FIRST test point (``latent_f_var[l][0]``)

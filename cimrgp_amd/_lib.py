@@ -40,8 +40,8 @@ SIGNATURES = {
     "cimrgp_lml_grad": (_i32, [_i32, _vp, _i64, _i32, _vp, _i64, _vp, _i32, _dbl, _dbl, _dbl, _vp, _vp, _vp]),
     "cimrgp_laplace_basis": (_i32, [_i32, _vp, _i64, _i32, _vp, _i32, _vp, _vp]),
     "cimrgp_basis_moments_scratch_bytes": (_sz, [_i64, _i32, _i32]),
-    "cimrgp_basis_moments": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
-    "cimrgp_basis_apply": (_i32, [_i32, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _dbl, _vp, _vp, _i32, _vp]),
+    "cimrgp_basis_moments": (_i32, [_i32, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "cimrgp_basis_apply": (_i32, [_i32, _vp, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _dbl, _vp, _vp, _i32, _vp]),
     "cimrgp_profile_begin": (_i32, []),
     "cimrgp_profile_collect": (_i32, [C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_i64)]),
 }

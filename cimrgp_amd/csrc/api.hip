@@ -293,31 +293,34 @@ int cimrgp_laplace_basis(int dtype, const void* x_dev, int64_t n, int d, const d
 size_t cimrgp_basis_moments_scratch_bytes(int64_t n, int m, int q)
 {
     if (n <= 0) return 0;
-    return (size_t)((n + 255) / 256) * (size_t)(m * q + 2 * m + q + 2) * sizeof(double);
+    return (size_t)basis_moments_workgroups(n) * (size_t)(m * q + 2 * m + q + 2) * sizeof(double);
 }
 
-int cimrgp_basis_moments(int dtype, const void* phi_dev, const void* y_dev, const void* fbar_dev, const void* fvar_dev,
-                         const double* eau_dev, int64_t n, int m, int q, double* out_dev, double* scratch_dev, void* stream)
+int cimrgp_basis_moments(int dtype, const void* x_dev, int64_t n, int d, const double* interval_dev, int m, const void* y_dev,
+                         const void* fbar_dev, const void* fvar_dev, const double* eau_dev, int q, double* out_dev,
+                         double* scratch_dev, void* stream)
 {
     const char* fn = "cimrgp_basis_moments";
-    CIMRGP_REQUIRE(phi_dev && y_dev && eau_dev && out_dev && scratch_dev, fn, "null pointer");
+    CIMRGP_REQUIRE(x_dev && interval_dev && y_dev && eau_dev && out_dev && scratch_dev, fn, "null pointer");
     DISPATCH(dtype, fn,
-             basis_moments_run<float>((const float*)phi_dev, (const float*)y_dev, (const float*)fbar_dev, (const float*)fvar_dev,
-                                      eau_dev, n, m, q, out_dev, scratch_dev, S(stream)),
-             basis_moments_run<double>((const double*)phi_dev, (const double*)y_dev, (const double*)fbar_dev,
-                                       (const double*)fvar_dev, eau_dev, n, m, q, out_dev, scratch_dev, S(stream)));
+             basis_moments_run<float>((const float*)x_dev, n, d, interval_dev, m, (const float*)y_dev, (const float*)fbar_dev,
+                                      (const float*)fvar_dev, eau_dev, q, out_dev, scratch_dev, S(stream)),
+             basis_moments_run<double>((const double*)x_dev, n, d, interval_dev, m, (const double*)y_dev,
+                                       (const double*)fbar_dev, (const double*)fvar_dev, eau_dev, q, out_dev, scratch_dev,
+                                       S(stream)));
 }
 
-int cimrgp_basis_apply(int dtype, const void* phi_dev, int64_t n, int m, const double* eau_dev, int q, const double* bias_dev,
-                       const double* c2_dev, double bias_var, void* mean_dev, void* var_dev, int accumulate, void* stream)
+int cimrgp_basis_apply(int dtype, const void* x_dev, int64_t n, int d, const double* interval_dev, int m, const double* eau_dev,
+                       int q, const double* bias_dev, const double* c2_dev, double bias_var, void* mean_dev, void* var_dev,
+                       int accumulate, void* stream)
 {
     const char* fn = "cimrgp_basis_apply";
-    CIMRGP_REQUIRE(phi_dev && eau_dev, fn, "null pointer");
+    CIMRGP_REQUIRE(x_dev && interval_dev && eau_dev, fn, "null pointer");
     DISPATCH(dtype, fn,
-             basis_apply_run<float>((const float*)phi_dev, n, m, eau_dev, q, bias_dev, c2_dev, bias_var, (float*)mean_dev,
-                                    (float*)var_dev, accumulate, S(stream)),
-             basis_apply_run<double>((const double*)phi_dev, n, m, eau_dev, q, bias_dev, c2_dev, bias_var, (double*)mean_dev,
-                                     (double*)var_dev, accumulate, S(stream)));
+             basis_apply_run<float>((const float*)x_dev, n, d, interval_dev, m, eau_dev, q, bias_dev, c2_dev, bias_var,
+                                    (float*)mean_dev, (float*)var_dev, accumulate, S(stream)),
+             basis_apply_run<double>((const double*)x_dev, n, d, interval_dev, m, eau_dev, q, bias_dev, c2_dev, bias_var,
+                                     (double*)mean_dev, (double*)var_dev, accumulate, S(stream)));
 }
 
 int cimrgp_profile_begin(void) { return profile_begin(); }

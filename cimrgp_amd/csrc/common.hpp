@@ -133,9 +133,11 @@ template <typename T> int lml_grad_run(const T* x, int64_t n, int d, const T* ki
 
 // reduced.hip
 template <typename T> int laplace_basis_run(const T* x, int64_t n, int d, const double* interval, int m, T* phi, hipStream_t st);
-template <typename T> int basis_moments_run(const T* phi, const T* y, const T* fbar, const T* fvar, const double* eau, int64_t n,
-                                            int m, int q, double* out, double* scratch, hipStream_t st);
-template <typename T> int basis_apply_run(const T* phi, int64_t n, int m, const double* eau, int q, const double* bias,
-                                          const double* c2, double bias_var, T* mean, T* var, int accumulate, hipStream_t st);
+int basis_moments_workgroups(int64_t n);
+template <typename T> int basis_moments_run(const T* x, int64_t n, int d, const double* interval, int m, const T* y, const T* fbar,
+                                            const T* fvar, const double* eau, int q, double* out, double* scratch, hipStream_t st);
+template <typename T> int basis_apply_run(const T* x, int64_t n, int d, const double* interval, int m, const double* eau, int q,
+                                          const double* bias, const double* c2, double bias_var, T* mean, T* var, int accumulate,
+                                          hipStream_t st);
 
 }  // namespace cimrgp

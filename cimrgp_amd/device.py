@@ -264,6 +264,8 @@ def laplace_basis(x, interval, n_basis, out=None):
     iv = _f64dev(np.asarray(interval, dtype=np.float64).reshape(-1), x.device)
     if iv.numel() != d:
         raise ValueError('Basis interval should have the same dimensionality as the input.')
+    if not x.is_contiguous():
+        raise ValueError("laplace_basis needs contiguous inputs")
     _lib.check(lib.cimrgp_laplace_basis(_DT[x.dtype], _p(x), n, d, _p(iv), int(n_basis), _p(out), _stream()),
                "cimrgp_laplace_basis")
     return out
@@ -283,35 +285,47 @@ class BlockMoments(object):
         self.n = int(n)
 
 
-def basis_moments(phi, y, fbar, fvar, eau):
-    """One pass over Phi: every N-dependent sum of the block's variational updates, with
-    r0 = y - fbar - Phi E[au]^T.  ``eau``: (q x m) host array.  Returns BlockMoments (host)."""
-    n, m = phi.shape
+def _interval_dev(interval, d, device):
+    iv = _f64dev(np.asarray(interval, dtype=np.float64).reshape(-1), device)
+    if iv.numel() != d:
+        raise ValueError('Basis interval should have the same dimensionality as the input.')
+    return iv
+
+
+def basis_moments(x, interval, n_basis, y, fbar, fvar, eau):
+    """Every N-dependent sum of one block's variational updates in one pass over the block's
+    points, with r0 = y - fbar - Phi E[au]^T; Phi is regenerated from ``x`` (n x d, device) and
+    the interval, never read.  ``eau``: (q x m) host array.  Returns BlockMoments (host)."""
+    n, d = x.shape
+    m = int(n_basis)
     q = y.shape[1]
     lib = _lib.load()
     rec_len = m * q + 2 * m + q + 2
-    out = torch.empty(rec_len, dtype=torch.float64, device=phi.device)
+    out = torch.empty(rec_len, dtype=torch.float64, device=x.device)
     scratch = torch.empty(max(lib.cimrgp_basis_moments_scratch_bytes(n, m, q), 8) // 8, dtype=torch.float64,
-                          device=phi.device)
-    e = _f64dev(eau, phi.device)
-    for t in (y, fbar, fvar):
+                          device=x.device)
+    e = _f64dev(eau, x.device)
+    iv = _interval_dev(interval, d, x.device)
+    for t in (x, y, fbar, fvar):
         if t is not None and not t.is_contiguous():
             raise ValueError("basis_moments needs contiguous operands")
-    _lib.check(lib.cimrgp_basis_moments(_DT[phi.dtype], _p(phi), _p(y), _p(fbar), _p(fvar), _p(e), n, m, q, _p(out),
+    _lib.check(lib.cimrgp_basis_moments(_DT[x.dtype], _p(x), n, d, _p(iv), m, _p(y), _p(fbar), _p(fvar), _p(e), q, _p(out),
                                         _p(scratch), _stream()), "cimrgp_basis_moments")
     return BlockMoments(out.cpu().numpy(), m, q, n)
 
 
-def basis_apply(phi, eau, bias=None, c2=None, bias_var=0.0, mean=None, var=None, accumulate=False):
-    """mean (+)= bias + Phi E[au]^T ;  var (+)= bias_var + Phi^2 c2."""
-    n, m = phi.shape
+def basis_apply(x, interval, n_basis, eau, bias=None, c2=None, bias_var=0.0, mean=None, var=None, accumulate=False):
+    """mean (+)= bias + Phi E[au]^T ;  var (+)= bias_var + Phi^2 c2, Phi regenerated from x."""
+    n, d = x.shape
     q = np.asarray(eau).shape[0]
     lib = _lib.load()
-    e = _f64dev(eau, phi.device)
-    b = None if bias is None else _f64dev(bias, phi.device)
-    c = None if c2 is None else _f64dev(c2, phi.device)
-    for t in (mean, var):
+    e = _f64dev(eau, x.device)
+    b = None if bias is None else _f64dev(bias, x.device)
+    c = None if c2 is None else _f64dev(c2, x.device)
+    iv = _interval_dev(interval, d, x.device)
+    for t in (x, mean, var):
         if t is not None and not t.is_contiguous():
-            raise ValueError("basis_apply needs contiguous outputs")
-    _lib.check(lib.cimrgp_basis_apply(_DT[phi.dtype], _p(phi), n, m, _p(e), q, _p(b), _p(c), float(bias_var), _p(mean),
-                                      _p(var), int(bool(accumulate)), _stream()), "cimrgp_basis_apply")
+            raise ValueError("basis_apply needs contiguous operands")
+    _lib.check(lib.cimrgp_basis_apply(_DT[x.dtype], _p(x), n, d, _p(iv), int(n_basis), _p(e), q, _p(b), _p(c),
+                                      float(bias_var), _p(mean), _p(var), int(bool(accumulate)), _stream()),
+               "cimrgp_basis_apply")

@@ -181,19 +181,25 @@ int cimrgp_lml_grad(int dtype, const void* x_dev, int64_t n, int d,
  * i = 1..m  (KernelClass.py:22-37, assembled as in MRGP.py:337-357).  interval_dev: d doubles. */
 int cimrgp_laplace_basis(int dtype, const void* x_dev, int64_t n, int d,
                          const double* interval_dev, int m, void* phi_dev, void* stream);
-/* The N-dependent sums of one block's variational updates (Posteriors.py:298-342,345-372,
+/* The two entry points below never read Phi: they regenerate each row from x and the
+ * interval (one sincos per input dimension + a three-term recurrence), so their HBM traffic
+ * is x, y, f_bar, f_var only.
+ *
+ * The N-dependent sums of one block's variational updates (Posteriors.py:298-342,345-372,
  * 396-412), with r0 = y - fbar - Phi E[au]^T (eau_dev: q x m doubles):
  *   out_dev = [ Phi^T r0 (m x q) | colsum Phi (m) | colsum Phi^2 (m) | sum r0 (q) |
  *               sum |r0|^2 (1) | sum fvar (1) ]   (doubles, fixed-order reduction)
  * fbar_dev / fvar_dev may be NULL.  scratch_dev: cimrgp_basis_moments_scratch_bytes(n, m, q). */
 size_t cimrgp_basis_moments_scratch_bytes(int64_t n, int m, int q);
-int cimrgp_basis_moments(int dtype, const void* phi_dev, const void* y_dev,
+int cimrgp_basis_moments(int dtype, const void* x_dev, int64_t n, int d,
+                         const double* interval_dev, int m, const void* y_dev,
                          const void* fbar_dev, const void* fvar_dev,
-                         const double* eau_dev, int64_t n, int m, int q,
+                         const double* eau_dev, int q,
                          double* out_dev, double* scratch_dev, void* stream);
 /* mean (n x q) (+)= bias + Phi E[au]^T ;  var (n) (+)= bias_var + Phi^2 c2
  * (Stats.py:316-348, MRGP.py:794-800,847-860).  mean_dev / var_dev / bias_dev / c2_dev may be NULL. */
-int cimrgp_basis_apply(int dtype, const void* phi_dev, int64_t n, int m,
+int cimrgp_basis_apply(int dtype, const void* x_dev, int64_t n, int d,
+                       const double* interval_dev, int m,
                        const double* eau_dev, int q, const double* bias_dev,
                        const double* c2_dev, double bias_var, void* mean_dev,
                        void* var_dev, int accumulate, void* stream);

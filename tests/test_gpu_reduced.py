@@ -42,56 +42,80 @@ def test_laplace_basis_kernel(ca, n, d, m, dtype):
     assert np.max(np.abs(phi - ref)) < (1e-12 if dtype == "f64" else 2e-5) * max(1.0, m)
 
 
-@pytest.mark.parametrize("n,m,q,latent", [(1, 1, 2, False), (255, 30, 2, True), (257, 64, 8, True), (5000, 40, 3, True),
-                                           (70001, 30, 2, False)])
+def _problem(rng, n, d, m, q, td):
+    x = rng.uniform(-1.2, 1.2, size=(n, d))
+    interval = 1.05 * np.max(np.abs(x), axis=0) + 0.01
+    xd = torch.as_tensor(x).to("cuda", td)
+    phi, _ = laplace_basis(xd.double().cpu().numpy(), interval, m)
+    return xd, interval, phi
+
+
+@pytest.mark.parametrize("n,d,m,q,latent", [(1, 1, 1, 2, False), (255, 1, 30, 2, True), (257, 2, 64, 8, True),
+                                             (5000, 3, 40, 3, True), (70001, 1, 30, 2, False), (333, 5, 7, 5, True),
+                                             (129, 1, 33, 4, True), (128, 4, 16, 1, True)])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-def test_basis_moments_kernel(ca, n, m, q, latent, dtype):
+def test_basis_moments_kernel(ca, n, d, m, q, latent, dtype):
     rng = np.random.default_rng(n * 7 + m)
     td = ca.device.as_torch_dtype(dtype)
-    phi = torch.as_tensor(rng.normal(size=(n, m))).to("cuda", td)
+    xd, interval, p = _problem(rng, n, d, m, q, td)
     y = torch.as_tensor(rng.normal(size=(n, q)) + 3.0).to("cuda", td)
     fbar = torch.as_tensor(rng.normal(size=(n, q))).to("cuda", td) if latent else None
     fvar = torch.as_tensor(rng.uniform(0, 1, size=n)).to("cuda", td) if latent else None
     eau = rng.normal(size=(q, m)) * 0.1
-    mom = ca.device.basis_moments(phi, y, fbar, fvar, eau)
-    p = phi.double().cpu().numpy()
+    mom = ca.device.basis_moments(xd, interval, m, y, fbar, fvar, eau)
     r0 = y.double().cpu().numpy() - (fbar.double().cpu().numpy() if latent else 0.0) - p @ eau.T
-    tol = TOL_F64 if dtype == "f64" else TOL_F32
-    scale = float(np.sqrt(n))
-    assert np.max(np.abs(mom.proj - p.T @ r0)) < tol * scale * 10
-    assert np.max(np.abs(mom.colsum - p.sum(0))) < tol * scale * 10
+    # Phi is generated in double from the (possibly f32) inputs: only y / f_bar carry f32 rounding,
+    # but they were rounded before this comparison too, so both precisions meet the f64 bar
+    tol = TOL_F64
+    scale = float(np.sqrt(n)) * 10
+    assert np.max(np.abs(mom.proj - p.T @ r0)) < tol * scale * (1 + np.max(np.abs(p.T @ r0)))
+    assert np.max(np.abs(mom.colsum - p.sum(0))) < tol * scale
     assert _rel(mom.colsum2, (p * p).sum(0)) < tol
     assert np.max(np.abs(mom.resid_sum - r0.sum(0))) < tol * n
     assert abs(mom.resid_sq - np.sum(r0 * r0)) < tol * np.sum(r0 * r0)
     assert abs(mom.fvar_sum - (fvar.double().sum().item() if latent else 0.0)) < tol * n
     assert mom.n == n
     # fixed-order reduction: bit-identical on repetition
-    again = ca.device.basis_moments(phi, y, fbar, fvar, eau)
+    again = ca.device.basis_moments(xd, interval, m, y, fbar, fvar, eau)
     assert np.array_equal(again.proj, mom.proj) and again.resid_sq == mom.resid_sq
 
 
-@pytest.mark.parametrize("n,m,q", [(1, 1, 2), (300, 30, 2), (4097, 64, 8)])
+@pytest.mark.parametrize("n,d,m,q", [(1, 1, 1, 2), (300, 1, 30, 2), (4097, 2, 64, 8), (1000, 6, 9, 3)])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-def test_basis_apply_kernel(ca, n, m, q, dtype):
+def test_basis_apply_kernel(ca, n, d, m, q, dtype):
     rng = np.random.default_rng(n + m + q)
     td = ca.device.as_torch_dtype(dtype)
-    phi = torch.as_tensor(rng.normal(size=(n, m))).to("cuda", td)
+    xd, interval, p = _problem(rng, n, d, m, q, td)
     eau, bias, c2 = rng.normal(size=(q, m)), rng.normal(size=q), rng.uniform(0, 1, size=m)
-    p = phi.double().cpu().numpy()
     want_mean = bias + p @ eau.T
     want_var = 0.25 + (p * p) @ c2
     mean = torch.full((n, q), 7.0, dtype=td, device="cuda")
     var = torch.full((n,), 7.0, dtype=td, device="cuda")
-    ca.device.basis_apply(phi, eau, bias, c2, 0.25, mean=mean, var=var, accumulate=False)
-    tol = 1e-12 if dtype == "f64" else 1e-5
+    ca.device.basis_apply(xd, interval, m, eau, bias, c2, 0.25, mean=mean, var=var, accumulate=False)
+    tol = 1e-11 if dtype == "f64" else 1e-5
     assert np.max(np.abs(mean.double().cpu().numpy() - want_mean)) < tol * m
     assert np.max(np.abs(var.double().cpu().numpy() - want_var)) < tol * m
-    ca.device.basis_apply(phi, eau, bias, c2, 0.25, mean=mean, var=var, accumulate=True)
+    ca.device.basis_apply(xd, interval, m, eau, bias, c2, 0.25, mean=mean, var=var, accumulate=True)
     assert np.max(np.abs(mean.double().cpu().numpy() - 2 * want_mean)) < 2 * tol * m
     assert np.max(np.abs(var.double().cpu().numpy() - 2 * want_var)) < 2 * tol * m
     only_mean = torch.zeros((n, q), dtype=td, device="cuda")
-    ca.device.basis_apply(phi, eau, None, None, 0.0, mean=only_mean)
+    ca.device.basis_apply(xd, interval, m, eau, None, None, 0.0, mean=only_mean)
     assert np.max(np.abs(only_mean.double().cpu().numpy() - p @ eau.T)) < tol * m
+
+
+def test_materialised_phi_matches_generated(ca, golden_dir):
+    """model.phi_x (direct sines, the reference's arithmetic) against what the fused kernels
+    regenerate by recurrence, through basis_apply with a one-hot coefficient."""
+    z = np.load(os.path.join(golden_dir, "reference_model_fi_r2.npz"))
+    model = _build(ca, z["x"], z["y"], 2, int(z["n_basis"]), True)
+    phi = model.phi_x
+    assert len(phi) == 3 and [len(p) for p in phi] == [1, 2, 4]
+    a, b = (int(v) for v in model.index_set_obj.bounds[2][3])
+    eau = np.zeros((2, model.n_basis))
+    eau[0, 29] = 1.0
+    out = torch.zeros((b - a, 2), dtype=torch.float64, device="cuda")
+    ca.device.basis_apply(model._x_dev[a:b], model.train_basis_intervals[2][3], model.n_basis, eau, mean=out)
+    assert np.max(np.abs(out[:, 0].cpu().numpy() - phi[2][3][:, 29].cpu().numpy())) < 1e-12
 
 
 def test_kernel_argument_errors(ca):

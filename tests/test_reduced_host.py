@@ -24,22 +24,25 @@ def _rel(a, b):
 
 @pytest.fixture
 def numpy_device(monkeypatch):
-    def laplace_basis(x, interval, n_basis, out=None):
+    def phi_of(x, interval, n_basis):
         xn = x.double().numpy()
         half = np.asarray(interval, dtype=np.float64)[None, :]
         cols = [np.prod(np.sin(np.pi * (i + 1) * (xn + half) / (2 * half)) / np.sqrt(half), axis=1) for i in range(n_basis)]
-        return torch.as_tensor(np.stack(cols, axis=1)).to(x.dtype)
+        return np.stack(cols, axis=1)
 
-    def basis_moments(phi, y, fbar, fvar, eau):
-        p = phi.double().numpy()
+    def laplace_basis(x, interval, n_basis, out=None):
+        return torch.as_tensor(phi_of(x, interval, n_basis)).to(x.dtype)
+
+    def basis_moments(x, interval, n_basis, y, fbar, fvar, eau):
+        p = phi_of(x, interval, n_basis)
         r0 = y.double().numpy() - (0 if fbar is None else fbar.double().numpy()) - p @ np.asarray(eau).T
         m, q = p.shape[1], r0.shape[1]
         rec = np.concatenate([(p.T @ r0).ravel(), p.sum(0), (p * p).sum(0), r0.sum(0), [np.sum(r0 * r0)],
                               [0.0 if fvar is None else float(fvar.double().sum())]])
         return dev.BlockMoments(rec, m, q, p.shape[0])
 
-    def basis_apply(phi, eau, bias=None, c2=None, bias_var=0.0, mean=None, var=None, accumulate=False):
-        p = phi.double().numpy()
+    def basis_apply(x, interval, n_basis, eau, bias=None, c2=None, bias_var=0.0, mean=None, var=None, accumulate=False):
+        p = phi_of(x, interval, n_basis)
         if mean is not None:
             mu = p @ np.asarray(eau).T + (0 if bias is None else np.asarray(bias))
             t = torch.as_tensor(mu).to(mean.dtype)

@@ -17,8 +17,9 @@ template <typename T> int misc_add_diag(T*, int64_t, int64_t, const T*, hipStrea
 template <typename T> int misc_noise_from_stats(const T*, int, double, double, T*, hipStream_t) { return 0; }
 template <typename T> int misc_logdet_half(const T*, int64_t, int64_t, double*, hipStream_t) { return 0; }
 template <typename T> int laplace_basis_run(const T*, int64_t, int, const double*, int, T*, hipStream_t) { return 0; }
-template <typename T> int basis_moments_run(const T*, const T*, const T*, const T*, const double*, int64_t, int, int, double*, double*, hipStream_t) { return 0; }
-template <typename T> int basis_apply_run(const T*, int64_t, int, const double*, int, const double*, const double*, double, T*, T*, int, hipStream_t) { return 0; }
+int basis_moments_workgroups(int64_t) { return 0; }
+template <typename T> int basis_moments_run(const T*, int64_t, int, const double*, int, const T*, const T*, const T*, const double*, int, double*, double*, hipStream_t) { return 0; }
+template <typename T> int basis_apply_run(const T*, int64_t, int, const double*, int, const double*, int, const double*, const double*, double, T*, T*, int, hipStream_t) { return 0; }
 template <typename T> int lml_grad_run(const T*, int64_t, int, const T*, int64_t, const T*, int, double, double, double, double*, double*, hipStream_t) { return 0; }
 }
 int main()
