@@ -27,7 +27,7 @@ defaults (region-specific noise and bias, non-informative priors, fixed basis in
 import numpy as np
 import torch
 from scipy.optimize import fsolve
-from scipy.special import gammaln, logsumexp, psi
+from scipy.special import gammaln, psi
 
 from . import device as dev
 from . import dist
@@ -36,6 +36,9 @@ from .KernelClass import LaplacianEigenpairs
 from .MRGP import MultiResolutionGaussianProcess
 
 EPSILON = 1e-45         # Priors.py:5
+#: 'minpack' = the reference's solver for the soft permutation (parity to rounding);
+#: 'sinkhorn' = converged log-domain Sinkhorn iteration, exact, ~1e-8 away.
+OMEGA_SOLVER = 'minpack'
 
 
 # =================================================================================================
@@ -84,23 +87,62 @@ def isPD(mat):
         return False
 
 
-def nearestPD(mat):
-    """Nearest symmetric positive-definite matrix (Higham 1988 via D'Errico's nearestSPD, the
-    variant in SanityCheck.py:17-57: polar factor from the SVD, then diagonal nudges of growing
-    size until Cholesky passes)."""
-    sym = 0.5 * (mat + mat.T)
+def _pd_mask(mats):
+    """Which matrices of a stack (B x p x p) pass Cholesky: the unblocked recursion LAPACK runs,
+    vectorised over the stack (a pivot <= 0 or NaN fails, as in dpotrf2)."""
+    batch, p = mats.shape[0], mats.shape[-1]
+    low = np.zeros_like(mats)
+    ok = np.ones(batch, dtype=bool)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        for j in range(p):
+            pivot = mats[:, j, j] - np.sum(low[:, j, :j] ** 2, axis=1)
+            ok &= pivot > 0                                   # NaN compares false
+            root = np.sqrt(np.where(pivot > 0, pivot, 1.0))
+            low[:, j, j] = root
+            for i in range(j + 1, p):
+                low[:, i, j] = (mats[:, i, j] - np.sum(low[:, i, :j] * low[:, j, :j], axis=1)) / root
+    return ok
+
+
+def nearestPD(mats):
+    """Nearest symmetric positive-definite matrix for every member of a stack (B x p x p), or
+    for a single matrix: Higham (1988) via D'Errico's nearestSPD as varied in
+    SanityCheck.py:17-57 -- polar factor from the SVD, then diagonal nudges of growing size,
+    -min_eig * k^2 + spacing(|A|_F), until Cholesky passes."""
+    single = mats.ndim == 2
+    stack = mats[None] if single else mats
+    sym = 0.5 * (stack + np.swapaxes(stack, 1, 2))
     _, sing, vt = np.linalg.svd(sym)
-    cand = 0.5 * (sym + (vt.T * sing) @ vt)
-    cand = 0.5 * (cand + cand.T)
-    if isPD(cand):
-        return cand
-    eps = np.spacing(np.linalg.norm(mat))
+    polar = np.einsum('bki,bk,bkj->bij', vt, sing, vt)
+    cand = 0.5 * (sym + polar)
+    cand = 0.5 * (cand + np.swapaxes(cand, 1, 2))
+    eps = np.spacing(np.sqrt(np.sum(stack * stack, axis=(1, 2))))
+    eye = np.eye(stack.shape[-1])
+    bad = np.flatnonzero(~_pd_mask(cand))
     k = 1
-    while not isPD(cand):
-        low = np.min(np.real(np.linalg.eigvals(cand)))
-        cand = cand + np.eye(mat.shape[0]) * (-low * k ** 2 + eps)
+    while bad.size:
+        low = np.min(np.real(np.linalg.eigvals(cand[bad])), axis=1)
+        cand[bad] += (-low * k ** 2 + eps[bad])[:, None, None] * eye
+        bad = bad[~_pd_mask(cand[bad])]
         k += 1
-    return cand
+    return cand[0] if single else cand
+
+
+def fit_axes(candidates):
+    """Posteriors.py:276-290 for a stack of candidate parameter matrices (B x p x p): repair the
+    ones that fail Cholesky, eigen-decompose (descending), normaliser and rho from the raw
+    eigenvalues, kappa clamped at zero afterwards.  Returns (b, kappa, axes, rho, log_const)."""
+    used = np.array(candidates, dtype=np.float64, copy=True)
+    bad = ~_pd_mask(used)
+    if np.any(bad):
+        used[bad] = nearestPD(used[bad])
+    vals, vecs = np.linalg.eig(used)
+    vals, vecs = np.real(vals), np.real(vecs)
+    order = np.argsort(vals, axis=1)[:, ::-1]
+    raw = np.take_along_axis(vals, order, axis=1)
+    axes = np.take_along_axis(vecs, order[:, None, :], axis=2)
+    log_c, rho = bingham_normaliser(raw)
+    return used, np.where(raw < 0, 0.0, raw), axes, rho, log_c
 
 
 class _AxisFactors(object):
@@ -115,22 +157,11 @@ class _AxisFactors(object):
         self.axis_bingham_rho = rho
         self.axis_bingham_log_const = log_c
 
-    def set_axes(self, candidates):
-        """Posteriors.py:276-290 for all m candidates (m x dy x dy): repair, eigen-decompose in
-        descending order, normaliser from the raw eigenvalues, kappa clamped at zero after."""
-        m = candidates.shape[0]
-        raw = np.empty_like(self.axis_bingham_kappa)
-        for i in range(m):
-            b = candidates[i]
-            if not isPD(b):
-                b = nearestPD(b)
-            self.axis_bingham_b[i] = b
-            vals, vecs = np.linalg.eig(b)
-            order = np.argsort(vals)[::-1]
-            raw[i] = np.real(vals[order])
-            self.axis_bingham_axes[i] = np.real(vecs[:, order])
-        self.axis_bingham_log_const, self.axis_bingham_rho = bingham_normaliser(raw)
-        self.axis_bingham_kappa = np.where(raw < 0, 0.0, raw)
+    def set_axes(self, candidates, fitted=None):
+        """Install the factors fitted to ``candidates`` (m x dy x dy); ``fitted`` lets a caller
+        that batched several regions through ``fit_axes`` hand the slice over."""
+        (self.axis_bingham_b, self.axis_bingham_kappa, self.axis_bingham_axes, self.axis_bingham_rho,
+         self.axis_bingham_log_const) = fit_axes(candidates) if fitted is None else fitted
 
     def cov(self):
         """E[u u^T] per factor = sum_d rho_d v_d v_d^T (Stats.py:249-257)."""
@@ -264,9 +295,16 @@ class IndependentPosterior(Posterior):
 
     def update_axis(self, prior, posterior, stats, regions=None):
         """Posteriors.py:257-290."""
-        for l in (range(self.n_regions) if regions is None else regions):
-            carried = np.tensordot(stats.omega[l], prior.axis_bingham_b[l], axes=1)
-            self.axis[l].set_axes(carried + self.axis_evidence(stats, regions=[l]))
+        regions = list(range(self.n_regions) if regions is None else regions)
+        if not regions:
+            return
+        prior_b = prior.axis_bingham_b
+        cands = np.concatenate([np.tensordot(stats.omega[l], prior_b[l], axes=1) + self.axis_evidence(stats, regions=[l])
+                                for l in regions])
+        fitted = fit_axes(cands)                 # one batched pass over all regions of the layer
+        m = self.n_basis
+        for k, l in enumerate(regions):
+            self.axis[l].set_axes(None, fitted=tuple(part[k * m:(k + 1) * m] for part in fitted))
 
     def update_ard(self, prior, stats, spectral_density, regions=None):
         """Posteriors.py:293-300 (the 0.5 * n_regions shape increment is the reference's)."""
@@ -409,13 +447,30 @@ class SharedStats(object):
             + (prior.ard_gamma_shape * np.log(prior.ard_gamma_scale) - gammaln(prior.ard_gamma_shape))[None, :] \
             + np.outer(self.ard_log_mean, prior.ard_gamma_shape - 1.0) - np.outer(self.ard_mean, prior.ard_gamma_scale)
 
+        def lse(mat, axis):
+            top = np.max(mat, axis=axis, keepdims=True)
+            return np.log(np.sum(np.exp(mat - top), axis=axis)) + np.squeeze(top, axis=axis)
+
         def residuals(ln_eta):
             ln_a, ln_b = ln_eta[:m], ln_eta[m:]
             out = np.empty(2 * m)
-            out[0::2] = ln_a + logsumexp(log_w + ln_b[None, :], axis=1)
-            out[1::2] = ln_b + logsumexp(log_w + ln_a[:, None], axis=0)
+            out[0::2] = ln_a + lse(log_w + ln_b[None, :], 1)
+            out[1::2] = ln_b + lse(log_w + ln_a[:, None], 0)
             return out
 
+        if OMEGA_SOLVER == 'sinkhorn':
+            # log-domain Sinkhorn on the same problem, run to convergence.  Exact
+            # where MINPACK stops at xtol = 1.5e-8, so the two agree to ~1e-8, not to rounding.
+            ln_a, ln_b = np.zeros(m), np.zeros(m)
+            for _ in range(10000):
+                ln_a = -lse(log_w + ln_b[None, :], 1)
+                ln_b_new = -lse(log_w + ln_a[:, None], 0)
+                done = np.max(np.abs(ln_b_new - ln_b)) < 1e-14
+                ln_b = ln_b_new
+                if done:
+                    break
+            self.omega = np.exp(ln_a[:, None] + ln_b[None, :] + log_w)
+            return
         ln_eta = fsolve(residuals, np.zeros(2 * m))
         self.omega = np.exp(ln_eta[:m, None] + ln_eta[None, m:] + log_w)
 
@@ -526,7 +581,7 @@ class ReducedRankMRGP(MultiResolutionGaussianProcess):
                 if self.spectral_density_obj[j] is None:
                     spec = np.ones(self.n_basis)
                 else:
-                    spec = np.array([self.spectral_density_obj[j].spectral(np.sqrt(v)) for v in lam], dtype=np.float64)
+                    spec = np.asarray(self.spectral_density_obj[j].spectral(np.sqrt(lam)), dtype=np.float64)   # MRGP.py:297-303
                 iv_j.append(interval)
                 lam_j.append(lam)
                 spec_j.append(spec)

@@ -134,3 +134,29 @@ def test_nearest_pd_and_axis_factors():
     # a strongly concentrated factor points along its evidence vector
     lead = ax.axis_bingham_axes[2][:, 0]
     assert abs(abs(lead @ (v[2] / np.linalg.norm(v[2]))) - 1.0) < 1e-9
+
+
+def test_sinkhorn_omega_agrees_with_minpack(monkeypatch):
+    """the converged Sinkhorn scaling is doubly stochastic to rounding and sits
+    within MINPACK's stopping tolerance of the reference's answer."""
+    rng = np.random.default_rng(11)
+    m, q = 12, 3
+    prior = rr.SharedPrior(m, q, 1.0)
+    v = rng.normal(size=(m, q))
+    prior.set_axes(np.einsum('ia,ib->iab', v, v) + 0.1 * np.eye(q))
+    prior.ard_gamma_shape = rng.uniform(0.5, 2.0, size=m)
+    prior.ard_gamma_scale = rng.uniform(0.5, 2.0, size=m)
+    post = rr.SharedPosterior(prior)
+    w = rng.normal(size=(m, q))
+    post.set_axes(np.einsum('ia,ib->iab', w, w) + 0.2 * np.eye(q))
+    post.ard_gamma_shape = rng.uniform(1.0, 3.0, size=m)
+    post.ard_gamma_scale = rng.uniform(1.0, 3.0, size=m)
+    stats = rr.SharedStats(post)
+    stats.update_axis(post)
+    stats.update_omega(prior)
+    ref = stats.omega.copy()
+    monkeypatch.setattr(rr, "OMEGA_SOLVER", "sinkhorn")
+    stats.update_omega(prior)
+    assert np.max(np.abs(stats.omega.sum(0) - 1.0)) < 1e-12 and np.max(np.abs(stats.omega.sum(1) - 1.0)) < 1e-12
+    assert np.max(np.abs(ref.sum(0) - 1.0)) < 1e-6
+    assert np.max(np.abs(stats.omega - ref)) < 1e-6 * np.max(ref)
