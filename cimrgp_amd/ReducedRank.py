@@ -21,8 +21,9 @@ names and attribute layout (lists over regions) so that code written against
                                                                  Priors.py:8,57  Posteriors.py:455,9  Stats.py:369,7
 
 Methods that took ``phi_x`` and ``y_mean`` in the reference take ``moments`` here: the list over
-regions of ``device.BlockMoments`` reduced on the GPU.  Supported configuration: the reference's
-defaults (region-specific noise and bias, non-informative priors, fixed basis intervals).
+regions of ``device.BlockMoments`` reduced on the GPU.  Supported: region-specific and shared
+noise / bias, fixed and adaptive basis intervals (``BasisInterval``), SNR-initialised noise,
+input warping, the lower bound of ``fit(n_iter, tol)``; priors are the non-informative ones.
 """
 import numpy as np
 import torch
@@ -31,6 +32,7 @@ from scipy.special import gammaln, psi
 
 from . import device as dev
 from . import dist
+from .BasisInterval import BasisInterval
 from .Inputs import Inputs
 from .KernelClass import LaplacianEigenpairs
 from .MRGP import MultiResolutionGaussianProcess
@@ -184,23 +186,34 @@ class SharedPrior(_AxisFactors):
 class Prior(object):
     """Priors.py:57-134: per-region scale, noise and bias priors."""
 
-    def __init__(self, n_basis, dy, n_regions, spectral_density, noise_var=None):
+    def __init__(self, n_basis, dy, n_regions, spectral_density, noise_var=None, noise_region_specific=True,
+                 bias_region_specific=True):
         self.n_basis, self.dy, self.n_regions = n_basis, dy, n_regions
-        self.noise_region_specific = True
-        self.bias_region_specific = True
+        self.noise_region_specific = noise_region_specific
+        self.bias_region_specific = bias_region_specific
         self.scale_precision = [1.0 / np.asarray(s) for s in spectral_density]
         noise_var = 1.0 if noise_var is None else noise_var
-        self.noise_gamma_shape = [EPSILON] * n_regions
-        self.noise_gamma_scale = [(EPSILON + 1.0) * noise_var] * n_regions
-        self.bias_normal_mean = [np.zeros(dy) for _ in range(n_regions)]
-        self.bias_normal_precision = [EPSILON] * n_regions
+        # a shared factor is one scalar / vector, a region-specific one a list (Priors.py:84-134)
+        if noise_region_specific:
+            self.noise_gamma_shape = [EPSILON] * n_regions
+            self.noise_gamma_scale = [(EPSILON + 1.0) * noise_var] * n_regions
+        else:
+            self.noise_gamma_shape = EPSILON
+            self.noise_gamma_scale = (EPSILON + 1.0) * noise_var
+        if bias_region_specific:
+            self.bias_normal_mean = [np.zeros(dy) for _ in range(n_regions)]
+            self.bias_normal_precision = [EPSILON] * n_regions
+        else:
+            self.bias_normal_mean = np.zeros(dy)
+            self.bias_normal_precision = EPSILON
 
 
 class IndependentPrior(Prior):
     """Priors.py:137-279: the same plus one axis/ARD prior set per region (fiMRGP)."""
 
-    def __init__(self, n_basis, dy, n_regions, spectral_density, prior_influence=1.0, noise_var=None):
-        Prior.__init__(self, n_basis, dy, n_regions, spectral_density, noise_var)
+    def __init__(self, n_basis, dy, n_regions, spectral_density, prior_influence=1.0, noise_var=None,
+                 noise_region_specific=True, bias_region_specific=True):
+        Prior.__init__(self, n_basis, dy, n_regions, spectral_density, noise_var, noise_region_specific, bias_region_specific)
         self.axis = [_AxisFactors(n_basis, dy) for _ in range(n_regions)]
         self.ard_gamma_shape = [EPSILON * np.ones(n_basis) for _ in range(n_regions)]
         self.ard_gamma_scale = [s / prior_influence for s in self.ard_gamma_shape]
@@ -217,20 +230,31 @@ class IndependentPrior(Prior):
 # =================================================================================================
 #  posteriors
 # =================================================================================================
+def _of(value, region, regional):
+    """A region's member of a factor that is either a list over regions or shared."""
+    return value[region] if regional else value
+
+
 class Posterior(object):
     """Per-region factors q(a|u), q(bias|tau), q(tau) of one layer (Posteriors.py:9-211)."""
 
     def __init__(self, prior):
         self.n_basis, self.dy, self.n_regions = prior.n_basis, prior.dy, prior.n_regions
-        self.noise_region_specific = True
-        self.bias_region_specific = True
+        self.noise_region_specific = prior.noise_region_specific
+        self.bias_region_specific = prior.bias_region_specific
         self.scale_precision = [p.copy() for p in prior.scale_precision]
         self.scale_mean_zeta = [np.zeros(self.n_basis) for _ in range(self.n_regions)]
         self.scale_mean_y_tilde = [np.zeros((self.dy, self.n_basis)) for _ in range(self.n_regions)]
-        self.noise_gamma_shape = list(prior.noise_gamma_shape)
-        self.noise_gamma_scale = list(prior.noise_gamma_scale)
-        self.bias_normal_mean = [b.copy() for b in prior.bias_normal_mean]
-        self.bias_normal_precision = list(prior.bias_normal_precision)
+        if self.noise_region_specific:
+            self.noise_gamma_shape = list(prior.noise_gamma_shape)
+            self.noise_gamma_scale = list(prior.noise_gamma_scale)
+        else:
+            self.noise_gamma_shape, self.noise_gamma_scale = prior.noise_gamma_shape, prior.noise_gamma_scale
+        if self.bias_region_specific:
+            self.bias_normal_mean = [b.copy() for b in prior.bias_normal_mean]
+            self.bias_normal_precision = list(prior.bias_normal_precision)
+        else:
+            self.bias_normal_mean, self.bias_normal_precision = prior.bias_normal_mean.copy(), prior.bias_normal_precision
 
     def _ard_mean(self, stats, shared_stats, region):
         return shared_stats.ard_mean
@@ -240,10 +264,11 @@ class Posterior(object):
         residual without i's own term:  Phi^T r + colsum(Phi^2) E[au],  r = r0 - bias."""
         for l in (range(self.n_regions) if regions is None else regions):
             mom = moments[l]
-            tau = stats.noise_mean[l]
+            tau = _of(stats.noise_mean, l, self.noise_region_specific)
+            bias = _of(stats.bias_mean, l, self.bias_region_specific)
             self.scale_precision[l] = self._ard_mean(stats, shared_stats, l) / spectral_density[l] + tau * mom.colsum2
             self.scale_mean_zeta[l] = tau / self.scale_precision[l]
-            self.scale_mean_y_tilde[l] = (mom.proj - np.outer(mom.colsum, stats.bias_mean[l])).T \
+            self.scale_mean_y_tilde[l] = (mom.proj - np.outer(mom.colsum, bias)).T \
                 + stats.scale_axis_mean[l] * mom.colsum2[None, :]
 
     def axis_evidence(self, stats, regions=None):
@@ -252,37 +277,76 @@ class Posterior(object):
         total = np.zeros((self.n_basis, self.dy, self.dy))
         for l in (range(self.n_regions) if regions is None else regions):
             yt = self.scale_mean_y_tilde[l]
-            total += (0.5 * stats.noise_mean[l] * self.scale_mean_zeta[l])[:, None, None] * np.einsum('ai,bi->iab', yt, yt)
+            tau = _of(stats.noise_mean, l, self.noise_region_specific)
+            total += (0.5 * tau * self.scale_mean_zeta[l])[:, None, None] * np.einsum('ai,bi->iab', yt, yt)
         return total
 
-    def update_bias_given_noise(self, moments, prior, stats, regions=None):
-        """Posteriors.py:75-91: ``moments`` taken with the *updated* E[au]."""
-        for l in (range(self.n_regions) if regions is None else regions):
-            self.bias_normal_precision[l] = prior.bias_normal_precision[l] + moments[l].n
-            self.bias_normal_mean[l] = (prior.bias_normal_mean[l] * prior.bias_normal_precision[l]
-                                        + moments[l].resid_sum) / self.bias_normal_precision[l]
+    def update_bias_given_noise(self, moments, prior, stats, regions=None, n_samps=None, reduce=None):
+        """Posteriors.py:75-110: ``moments`` taken with the *updated* E[au].  A shared bias pools
+        the residual sums of all regions (``reduce`` adds the other ranks' share, ``n_samps`` is
+        the size of every region of the layer)."""
+        regions = range(self.n_regions) if regions is None else regions
+        if self.bias_region_specific:
+            for l in regions:
+                self.bias_normal_precision[l] = prior.bias_normal_precision[l] + moments[l].n
+                self.bias_normal_mean[l] = (prior.bias_normal_mean[l] * prior.bias_normal_precision[l]
+                                            + moments[l].resid_sum) / self.bias_normal_precision[l]
+            return
+        pooled = np.zeros(self.dy)
+        for l in regions:
+            pooled = pooled + moments[l].resid_sum
+        if reduce is not None:
+            pooled = reduce(pooled)
+        total_n = sum(moments[l].n for l in regions) if n_samps is None else sum(n_samps)
+        self.bias_normal_precision = prior.bias_normal_precision + total_n
+        self.bias_normal_mean = (prior.bias_normal_mean * prior.bias_normal_precision + pooled) / self.bias_normal_precision
 
-    #: the reference multiplies the target variance by n in the independent flavour only
-    _y_var_times_n = False
+    def _y_var_times_n(self):
+        """Whether the target variance enters the noise update multiplied by the block size:
+        not in the all-regional variant, yes in the other three (Posteriors.py:135,158,176,199)."""
+        return not (self.noise_region_specific and self.bias_region_specific)
 
-    def update_noise(self, moments, y_var, prior, posterior, stats, regions=None):
-        """Posteriors.py:128-146 (region-specific noise and bias).  The residual of the mean
-        term carries no bias; the bias enters as precision * |mean|^2 (``term4``)."""
-        for l in (range(self.n_regions) if regions is None else regions):
+    def update_noise(self, moments, y_var, prior, posterior, stats, regions=None, n_samps=None, reduce=None):
+        """Posteriors.py:113-211, the four region-specific / shared combinations.  The residual of
+        the mean term carries no bias; the bias enters as precision * |mean|^2 (``term4``)."""
+        regions = list(range(self.n_regions) if regions is None else regions)
+        times_n = self._y_var_times_n()
+
+        def bias_terms(l):
+            p0 = _of(prior.bias_normal_precision, l, self.bias_region_specific)
+            w0 = _of(prior.bias_normal_mean, l, self.bias_region_specific)
+            p1 = _of(posterior.bias_normal_precision, l, self.bias_region_specific)
+            w1 = _of(posterior.bias_normal_mean, l, self.bias_region_specific)
+            return p0 * float(np.dot(w0, w0)) - p1 * float(np.dot(w1, w1))
+
+        def data_terms(l):
             mom = moments[l]
-            self.noise_gamma_shape[l] = prior.noise_gamma_shape[l] + 0.5 * self.dy * mom.n
-            term3 = prior.bias_normal_precision[l] * float(np.dot(prior.bias_normal_mean[l], prior.bias_normal_mean[l]))
-            term4 = posterior.bias_normal_precision[l] * float(np.dot(posterior.bias_normal_mean[l],
-                                                                      posterior.bias_normal_mean[l]))
             var_au = float(np.dot(mom.colsum2, stats.scale_axis_central_moment2[l]))
-            y_var_l = y_var[l] * mom.n if self._y_var_times_n else y_var[l]
-            self.noise_gamma_scale[l] = prior.noise_gamma_scale[l] + 0.5 * (term3 - term4 + mom.resid_sq + mom.fvar_sum
-                                                                          + var_au + y_var_l)
+            return mom.resid_sq + mom.fvar_sum + var_au + (y_var[l] * mom.n if times_n else y_var[l])
+
+        if self.noise_region_specific:
+            for l in regions:
+                self.noise_gamma_shape[l] = prior.noise_gamma_shape[l] + 0.5 * self.dy * moments[l].n
+                self.noise_gamma_scale[l] = prior.noise_gamma_scale[l] + 0.5 * (bias_terms(l) + data_terms(l))
+            return
+        pooled = sum(data_terms(l) for l in regions)
+        if self.bias_region_specific:
+            pooled += sum(bias_terms(l) for l in regions)
+        if reduce is not None:
+            pooled = float(reduce(np.array([pooled]))[0])
+        if not self.bias_region_specific:
+            pooled += bias_terms(0)
+        total_n = sum(moments[l].n for l in regions) if n_samps is None else sum(n_samps)
+        self.noise_gamma_shape = prior.noise_gamma_shape + 0.5 * self.dy * total_n
+        self.noise_gamma_scale = prior.noise_gamma_scale + 0.5 * pooled
 
 
 class IndependentPosterior(Posterior):
     """Posteriors.py:215-452: every region also owns its axes and ARD weights."""
-    _y_var_times_n = True
+
+    def _y_var_times_n(self):
+        """Posteriors.py:402,422,440,463: multiplied by n except with regional noise + shared bias."""
+        return not (self.noise_region_specific and not self.bias_region_specific)
 
     def __init__(self, prior):
         Posterior.__init__(self, prior)
@@ -355,8 +419,8 @@ class Stats(object):
     def __init__(self, posterior):
         qd = posterior
         self.n_basis, self.dy, self.n_regions = qd.n_basis, qd.dy, qd.n_regions
-        self.noise_region_specific = True
-        self.bias_region_specific = True
+        self.noise_region_specific = qd.noise_region_specific
+        self.bias_region_specific = qd.bias_region_specific
         self.scale_axis_mean = [np.zeros((self.dy, self.n_basis)) for _ in range(self.n_regions)]
         self.scale_moment2 = [np.zeros(self.n_basis) for _ in range(self.n_regions)]
         self.scale_axis_central_moment2 = [np.zeros(self.n_basis) for _ in range(self.n_regions)]
@@ -366,6 +430,19 @@ class Stats(object):
         self.bias_var = [0.0] * self.n_regions
         self.update_noise(qd)
         self.update_bias(qd)
+
+    # a region's view of factors that may be shared
+    def noise_of(self, region):
+        return _of(self.noise_mean, region, self.noise_region_specific)
+
+    def noise_log_of(self, region):
+        return _of(self.noise_log_mean, region, self.noise_region_specific)
+
+    def bias_of(self, region):
+        return _of(self.bias_mean, region, self.bias_region_specific)
+
+    def bias_var_of(self, region):
+        return _of(self.bias_var, region, self.bias_region_specific)
 
     def _axis_cov(self, stats, region):
         return stats.axis_cov
@@ -385,11 +462,21 @@ class Stats(object):
             self.scale_axis_central_moment2[l] = inv_prec + zeta ** 2 * (quad - quad_sq)
 
     def update_noise(self, posterior, regions=None):
+        """Stats.py:102-112."""
+        if not self.noise_region_specific:
+            self.noise_mean = posterior.noise_gamma_shape / posterior.noise_gamma_scale
+            self.noise_log_mean = psi(posterior.noise_gamma_shape) - np.log(posterior.noise_gamma_scale)
+            return
         for l in (range(self.n_regions) if regions is None else regions):
             self.noise_mean[l] = posterior.noise_gamma_shape[l] / posterior.noise_gamma_scale[l]
             self.noise_log_mean[l] = psi(posterior.noise_gamma_shape[l]) - np.log(posterior.noise_gamma_scale[l])
 
     def update_bias(self, posterior, regions=None):
+        """Stats.py:114-124."""
+        if not self.bias_region_specific:
+            self.bias_mean = posterior.bias_normal_mean
+            self.bias_var = 1.0 / posterior.bias_normal_precision
+            return
         for l in (range(self.n_regions) if regions is None else regions):
             self.bias_mean[l] = posterior.bias_normal_mean[l]
             self.bias_var[l] = 1.0 / posterior.bias_normal_precision[l]
@@ -510,8 +597,9 @@ class ReducedRankMRGP(MultiResolutionGaussianProcess):
             if axis_resolution_specific or ard_resolution_specific:
                 raise TypeError("not yet supported")                     # MRGP.py:50-51
             self.axis_resolution_specific = self.ard_resolution_specific = False
-        if noise_region_specific is not True or bias_region_specific is not True:
-            raise TypeError("not yet supported")     # shared noise/bias variants: not built yet
+        for flag in (noise_region_specific, bias_region_specific):
+            if flag is not True and flag is not False:
+                raise TypeError('region_specific can be either True or False.')       # Priors.py:102,134
         if noninformative_initialization is not True:
             raise ValueError('not yet implemented...')                   # Priors.py:26
         if index_set_obj is None or n_basis is None:
@@ -520,13 +608,11 @@ class ReducedRankMRGP(MultiResolutionGaussianProcess):
             raise ValueError('n_basis must be at most 64 on this path')
         if self.forced_independence:
             basis_interval_obj = None                                    # MRGP.py:110-111
-        if basis_interval_obj is not None:
-            raise TypeError("not yet supported")     # adaptive basis intervals (BasisInterval.learn)
-        self.adaptive_basis_intervals = False
+        self.adaptive_basis_intervals = basis_interval_obj is not None               # MRGP.py:113-129
         self.adaptive_inputs = adaptive_inputs
         self.standard_normalized_inputs = standard_normalized_inputs
-        self.noise_region_specific = True
-        self.bias_region_specific = True
+        self.noise_region_specific = noise_region_specific
+        self.bias_region_specific = bias_region_specific
 
         self.n_layers = index_set_obj.get_n_resolutions() + 1
         self.index_set_obj = index_set_obj
@@ -549,6 +635,8 @@ class ReducedRankMRGP(MultiResolutionGaussianProcess):
             if not isinstance(b, LaplacianEigenpairs):
                 raise TypeError('basis_function_obj must be LaplacianEigenpairs')
         self.interval_factor = self._per_layer(interval_factor, 'interval_factor')
+        self.basis_interval_obj = [BasisInterval() for _ in range(self.n_layers)] if basis_interval_obj is None \
+            else self._per_layer(basis_interval_obj, 'basis_interval_obj')
         self.use_prior = [s is not None for s in self.spectral_density_obj]
 
         self.device = dev.require_gpu(device)
@@ -571,17 +659,13 @@ class ReducedRankMRGP(MultiResolutionGaussianProcess):
 
         # basis intervals, eigenvalues, prior spectral weights (MRGP.py:136-176,297-335) and Phi on the GPU
         self.train_basis_intervals, self.lambda_, self.spectral_density_prior = [], [], []
-        orders = np.arange(1, self.n_basis + 1, dtype=np.float64)
+        self._x_host = x_host
         for j in range(self.n_layers):
             iv_j, lam_j, spec_j = [], [], []
             for l, (a, b) in enumerate(bounds[j]):
                 a, b = int(a), int(b)
-                interval = self.interval_factor[j] * np.max(np.abs(x_host[a:b]), axis=0)     # BasisInterval.py:15-16
-                lam = np.sum((np.pi * orders[:, None] / (2.0 * interval[None, :])) ** 2, axis=1)
-                if self.spectral_density_obj[j] is None:
-                    spec = np.ones(self.n_basis)
-                else:
-                    spec = np.asarray(self.spectral_density_obj[j].spectral(np.sqrt(lam)), dtype=np.float64)   # MRGP.py:297-303
+                interval = self.basis_interval_obj[j].max_input_range_by_factor_of(x_host[a:b], self.interval_factor[j])
+                lam, spec = self._eigenvalues_and_prior(j, interval)
                 iv_j.append(interval)
                 lam_j.append(lam)
                 spec_j.append(spec)
@@ -596,11 +680,13 @@ class ReducedRankMRGP(MultiResolutionGaussianProcess):
         for j in range(self.n_layers):
             nv = noise_var0 if j == 0 else None
             if self.forced_independence:
-                pr = IndependentPrior(self.n_basis, self.dy, self.n_regions[j], self.spectral_density_prior[j], influence, nv)
+                pr = IndependentPrior(self.n_basis, self.dy, self.n_regions[j], self.spectral_density_prior[j], influence, nv,
+                                      noise_region_specific, bias_region_specific)
                 po = IndependentPosterior(pr)
                 st = IndependentStats(po)
             else:
-                pr = Prior(self.n_basis, self.dy, self.n_regions[j], self.spectral_density_prior[j], nv)
+                pr = Prior(self.n_basis, self.dy, self.n_regions[j], self.spectral_density_prior[j], nv,
+                           noise_region_specific, bias_region_specific)
                 po = Posterior(pr)
                 st = Stats(po)
             self.prior_obj.append(pr)
@@ -616,9 +702,18 @@ class ReducedRankMRGP(MultiResolutionGaussianProcess):
         zero_v = torch.zeros(n0, dtype=self.dtype, device=self.device)
         self._latent = [(zero_f, zero_v) for _ in range(self.n_layers)]
         self.y_var = [[0.0] * self.n_regions[j] for j in range(self.n_layers)]
+        self._targets = [dict() for _ in range(self.n_layers)]
         self._fitted = False
         self.lower_bound = []
         self.lower_bound_layer = [[] for _ in range(self.n_layers)]
+
+    def _eigenvalues_and_prior(self, j, interval):
+        """lambda_i = sum_k (pi i / 2 L_k)^2 and the prior weight S(sqrt(lambda_i)) (MRGP.py:297-357)."""
+        orders = np.arange(1, self.n_basis + 1, dtype=np.float64)
+        lam = np.sum((np.pi * orders[:, None] / (2.0 * np.asarray(interval, dtype=np.float64)[None, :])) ** 2, axis=1)
+        if self.spectral_density_obj[j] is None:
+            return lam, np.ones(self.n_basis)
+        return lam, np.asarray(self.spectral_density_obj[j].spectral(np.sqrt(lam)), dtype=np.float64)
 
     def _per_layer(self, obj, name):
         if isinstance(obj, list):
@@ -629,14 +724,80 @@ class ReducedRankMRGP(MultiResolutionGaussianProcess):
 
     # ------------------------------------------------------------------------------- fitting
     def fit(self, n_iter=1, tol=1e-3, min_iter=10):
-        """MRGP.py:367-414.  The reference's ``tol`` branch stops on the change of its lower
-        bound, which this path does not evaluate: ``n_iter`` sweeps are run either way."""
-        for _ in range(int(n_iter)):
+        """MRGP.py:367-412.  With ``tol`` ciMRGP records its lower bound after every sweep and
+        stops once, past ``min_iter`` sweeps, layer 0's bound moves by less than ``tol``;
+        fiMRGP runs ``n_iter`` sweeps either way (as in the reference)."""
+        n_iter = int(n_iter)
+        min_iter = min(min_iter, n_iter)
+        for it in range(1, n_iter + 1):
             if self.forced_independence:
                 self._independent_fit()
-            else:
-                self._fit()
+                continue
+            self._fit()
+            if tol is None:
+                continue
+            total, per_layer = self._compute_lower_bound()
+            self.lower_bound.append(total)
+            for j in range(self.n_layers):
+                self.lower_bound_layer[j].append(per_layer[j])
+            if it > min_iter:
+                delta0 = self.lower_bound_layer[0][-1] - self.lower_bound_layer[0][-2]
+                if self.verbose:
+                    print("\nTotal ELBO: %.4f ... dELBO %.4f" % (self.lower_bound[-1], self.lower_bound[-1] - self.lower_bound[-2]))
+                if abs(delta0) < abs(tol):
+                    break
         self._fitted = True
+
+    def _compute_lower_bound(self):
+        """MRGP.py:414-571, term by term as the reference codes it: the data term is the bare sum
+        of squared errors and variances plus the log-normaliser; the axis term multiplies its two
+        matrices elementwise before the trace; for j > 0 the "previous" shared posterior is the
+        current one (``_fit_tol`` aliases it, MRGP.py:379).  One more pass of the moments kernel
+        per block supplies the squared residual under the final statistics."""
+        sp, ss = self.shared_posterior, self.shared_stats
+        per_layer = []
+        diag_cov = np.einsum('iaa->ia', ss.axis_cov)
+
+        def gamma_term(shape, scale, log_mean, mean):
+            return shape * np.log(scale) - gammaln(shape) + (shape - 1) * log_mean - scale * mean
+
+        for j in range(self.n_layers):
+            po, pr, st = self.posterior_obj[j], self.prior_obj[j], self.stats_obj[j]
+            prev = self.shared_prior if j == 0 else sp
+            owned = self._owned(j)
+            mom = self._moments(j, owned, self._targets[j])
+            local = 0.0
+            for l in owned:
+                mm, bias = mom[l], st.bias_of(l)
+                sq = mm.resid_sq - 2.0 * float(np.dot(bias, mm.resid_sum)) + mm.n * float(np.dot(bias, bias))
+                local += sq + mm.fvar_sum + float(np.dot(mm.colsum2, st.scale_axis_central_moment2[l]))
+                local += np.sum(0.5 * ss.ard_log_mean / self.spectral_density_prior[j][l]
+                                - 0.5 * ss.ard_mean * st.scale_moment2[l] / self.spectral_density_prior[j][l])
+                local -= np.sum(0.5 * np.log(po.scale_precision[l]) - 0.5)
+            total = float(self._sum_over_ranks(np.array([local]))[0])
+            for l in range(self.n_regions[j]):
+                n_l = self.n_samps[j][l]
+                tau, log_tau = st.noise_of(l), st.noise_log_of(l)
+                total += st.bias_var_of(l) + self.y_var[j][l] * n_l + 0.5 * self.dy * (log_tau - np.log(2 * np.pi)) * n_l
+                w = st.bias_of(l)
+                p0 = _of(pr.bias_normal_precision, l, self.bias_region_specific)
+                w0 = _of(pr.bias_normal_mean, l, self.bias_region_specific)
+                p1 = _of(po.bias_normal_precision, l, self.bias_region_specific)
+                spread = 1.0 / (p1 * tau) + np.dot(w, w) - 2 * np.dot(w, w0) + np.dot(w0, w0)
+                total += 0.5 * self.dy * (np.log(p0) + log_tau - np.log(2 * np.pi)) + 0.5 * p0 * tau * spread
+                total -= 0.5 * self.dy * (np.log(p1) + log_tau - np.log(2 * np.pi)) - 0.5
+                total += gamma_term(_of(pr.noise_gamma_shape, l, self.noise_region_specific),
+                                    _of(pr.noise_gamma_scale, l, self.noise_region_specific), log_tau, tau)
+                total -= gamma_term(_of(po.noise_gamma_shape, l, self.noise_region_specific),
+                                    _of(po.noise_gamma_scale, l, self.noise_region_specific), log_tau, tau)
+            prev_diag = np.einsum('kaa->ka', prev.axis_bingham_b)
+            total += np.sum(ss.omega * (-prev.axis_bingham_log_const[None, :] + diag_cov @ prev_diag.T))
+            total -= np.sum(-sp.axis_bingham_log_const + np.sum(diag_cov * np.einsum('iaa->ia', sp.axis_bingham_b), axis=1))
+            total += np.sum(ss.omega * gamma_term(prev.ard_gamma_shape[None, :], prev.ard_gamma_scale[None, :],
+                                                  ss.ard_log_mean[:, None], ss.ard_mean[:, None]))
+            total -= np.sum(gamma_term(sp.ard_gamma_shape, sp.ard_gamma_scale, ss.ard_log_mean, ss.ard_mean))
+            per_layer.append(float(total))
+        return float(np.sum(per_layer)), per_layer
 
     @property
     def phi_x(self):
@@ -669,7 +830,7 @@ class ReducedRankMRGP(MultiResolutionGaussianProcess):
         for l in owned:
             a, b = (int(t) for t in self.index_set_obj.bounds[j][l])
             dev.basis_apply(self._x_dev[a:b], self.train_basis_intervals[j][l], self.n_basis, st.scale_axis_mean[l],
-                            st.bias_mean[l], st.scale_axis_central_moment2[l], st.bias_var[l], mean=delta_f[a:b],
+                            st.bias_of(l), st.scale_axis_central_moment2[l], st.bias_var_of(l), mean=delta_f[a:b],
                             var=delta_v[a:b], accumulate=False)
         if self.world_size > 1:
             fused[:, :self.dy] = delta_f
@@ -679,17 +840,20 @@ class ReducedRankMRGP(MultiResolutionGaussianProcess):
         self._latent[j + 1] = (f + delta_f, v + delta_v)
 
     def _sync_regions(self, j):
-        """Multi-GPU: every rank needs every region's host statistics (a few kB per region)."""
+        """Multi-GPU: every rank needs every region's host statistics (a few kB per region);
+        shared noise / bias factors are already identical everywhere."""
         if self.world_size == 1:
             return
         po, st = self.posterior_obj[j], self.stats_obj[j]
         m, q = self.n_basis, self.dy
-        width = q * m + 2 * m + q + 4
+        width = q * m + 3 * m + q + 5
         buf = torch.zeros((self.n_regions[j], width), dtype=torch.float64, device=self.device)
         for l in self._owned(j):
             row = np.concatenate([st.scale_axis_mean[l].ravel(), st.scale_moment2[l], st.scale_axis_central_moment2[l],
-                                  np.asarray(st.bias_mean[l]).ravel(),
-                                  [st.bias_var[l], st.noise_mean[l], po.noise_gamma_shape[l], po.noise_gamma_scale[l]]])
+                                  po.scale_precision[l], np.asarray(st.bias_of(l)).ravel(),
+                                  [st.bias_var_of(l), st.noise_of(l), st.noise_log_of(l),
+                                   _of(po.noise_gamma_shape, l, self.noise_region_specific),
+                                   _of(po.noise_gamma_scale, l, self.noise_region_specific)]])
             buf[l] = torch.as_tensor(row).to(self.device)
         dist.allreduce_sum_(buf, self.group)
         host = buf.cpu().numpy()
@@ -700,9 +864,15 @@ class ReducedRankMRGP(MultiResolutionGaussianProcess):
             st.scale_axis_mean[l] = row[:q * m].reshape(q, m)
             st.scale_moment2[l] = row[q * m:q * m + m]
             st.scale_axis_central_moment2[l] = row[q * m + m:q * m + 2 * m]
-            st.bias_mean[l] = row[q * m + 2 * m:q * m + 2 * m + q]
-            st.bias_var[l], st.noise_mean[l] = row[-4], row[-3]
-            po.noise_gamma_shape[l], po.noise_gamma_scale[l] = row[-2], row[-1]
+            po.scale_precision[l] = row[q * m + 2 * m:q * m + 3 * m]
+            if self.bias_region_specific:
+                st.bias_mean[l] = row[q * m + 3 * m:q * m + 3 * m + q]
+                st.bias_var[l] = row[-5]
+                po.bias_normal_mean[l] = st.bias_mean[l]
+                po.bias_normal_precision[l] = 1.0 / row[-5]
+            if self.noise_region_specific:
+                st.noise_mean[l], st.noise_log_mean[l] = row[-4], row[-3]
+                po.noise_gamma_shape[l], po.noise_gamma_scale[l] = row[-2], row[-1]
 
     def _independent_fit(self):
         """One sweep of fiMRGP (MRGP.py:663-731); targets are the observations of the region
@@ -721,8 +891,8 @@ class ReducedRankMRGP(MultiResolutionGaussianProcess):
             po.update_ard(pr, st, self.spectral_density_prior[j], regions=owned)
             st.update_ard(po, regions=owned)
             mom = self._moments(j, owned, targets)                     # residuals under the new E[au]
-            po.update_bias_given_noise(mom, pr, st, regions=owned)
-            po.update_noise(mom, y_var, pr, po, st, regions=owned)
+            po.update_bias_given_noise(mom, pr, st, regions=owned, n_samps=self.n_samps[j], reduce=self._sum_over_ranks)
+            po.update_noise(mom, y_var, pr, po, st, regions=owned, n_samps=self.n_samps[j], reduce=self._sum_over_ranks)
             st.update_bias(po, regions=owned)
             st.update_noise(po, regions=owned)
             self.y_var[j] = y_var
@@ -741,7 +911,7 @@ class ReducedRankMRGP(MultiResolutionGaussianProcess):
             y_var = [0.0] * self.n_regions[j]
             for l in range(self.n_regions[j]):
                 if j > 0:
-                    y_var[l] = 1.0 / st.noise_mean[l]
+                    y_var[l] = 1.0 / st.noise_of(l)
             for l in owned:
                 a, b, fbar, _ = self._block_views(j, l)
                 if j == 0:
@@ -749,8 +919,9 @@ class ReducedRankMRGP(MultiResolutionGaussianProcess):
                 else:
                     t = fbar.clone()
                     dev.basis_apply(self._x_dev[a:b], self.train_basis_intervals[j][l], self.n_basis, st.scale_axis_mean[l],
-                                    st.bias_mean[l], mean=t, accumulate=True)
+                                    st.bias_of(l), mean=t, accumulate=True)
                     targets[l] = t
+            self._targets[j] = targets
             previous = self.shared_prior if j == 0 else self.shared_posterior.snapshot()
 
             mom = self._moments(j, owned, targets)
@@ -767,14 +938,28 @@ class ReducedRankMRGP(MultiResolutionGaussianProcess):
             self.shared_stats.update_ard(self.shared_posterior)
             self.shared_stats.update_omega(previous, self.shared_stats)
             mom = self._moments(j, owned, targets)
-            po.update_bias_given_noise(mom, pr, st, regions=owned)
-            po.update_noise(mom, y_var, pr, po, st, regions=owned)
+            po.update_bias_given_noise(mom, pr, st, regions=owned, n_samps=self.n_samps[j], reduce=self._sum_over_ranks)
+            po.update_noise(mom, y_var, pr, po, st, regions=owned, n_samps=self.n_samps[j], reduce=self._sum_over_ranks)
             st.update_bias(po, regions=owned)
             st.update_noise(po, regions=owned)
             self.y_var[j] = y_var
             self._sync_regions(j)
+            if self.adaptive_basis_intervals:                            # MRGP.py:626-636
+                self._learn_basis_intervals(j, owned, targets)
             if j + 1 < self.n_layers:
                 self._update_latent_functions(j, owned)
+
+    def _learn_basis_intervals(self, j, owned, targets):
+        """New intervals for the layer's regions (BasisInterval.learn), then eigenvalues and
+        prior spectral weights rebuilt from them; Phi itself is never stored."""
+        d = self.dx
+        fresh = np.zeros((self.n_regions[j], d))
+        for l in owned:
+            fresh[l] = self.basis_interval_obj[j].learn(self, j, l, targets[l])
+        fresh = self._sum_over_ranks(fresh)
+        for l in range(self.n_regions[j]):
+            self.train_basis_intervals[j][l] = fresh[l].copy()
+            self.lambda_[j][l], self.spectral_density_prior[j][l] = self._eigenvalues_and_prior(j, fresh[l])
 
     def _sum_over_ranks(self, host_array):
         if self.world_size == 1:
@@ -795,8 +980,8 @@ class ReducedRankMRGP(MultiResolutionGaussianProcess):
             # every prediction is taken from resolution 0 (MRGP.py:733-762, 832-860)
             if self.owner[0][0] == self.rank:
                 st = self.stats_obj[0]
-                dev.basis_apply(xs, self.train_basis_intervals[0][0], self.n_basis, st.scale_axis_mean[0], st.bias_mean[0],
-                                st.scale_axis_central_moment2[0], st.bias_var[0], mean=mean, var=total, accumulate=False)
+                dev.basis_apply(xs, self.train_basis_intervals[0][0], self.n_basis, st.scale_axis_mean[0], st.bias_of(0),
+                                st.scale_axis_central_moment2[0], st.bias_var_of(0), mean=mean, var=total, accumulate=False)
         else:
             n_layers = index_set.get_n_resolutions() + 1
             coarser = torch.zeros(ns, dtype=self.dtype, device=self.device) if want_var else None
@@ -806,12 +991,12 @@ class ReducedRankMRGP(MultiResolutionGaussianProcess):
                 for l in self._owned(j):
                     a, b = (int(v) for v in index_set.bounds[j][l])
                     dev.basis_apply(xs[a:b], self.train_basis_intervals[j][l], self.n_basis, st.scale_axis_mean[l],
-                                    st.bias_mean[l], st.scale_axis_central_moment2[l], st.bias_var[l], mean=mean[a:b],
+                                    st.bias_of(l), st.scale_axis_central_moment2[l], st.bias_var_of(l), mean=mean[a:b],
                                     var=own[a:b] if want_var else None, accumulate=True)
                     if want_var:
                         # MRGP.py:905-937: own term + n_l / E[tau] + the coarser layers' variance at the
                         # region's FIRST test point (``latent_f_var[l][0]``)
-                        total[a:b] += own[a:b] + (b - a) / st.noise_mean[l]
+                        total[a:b] += own[a:b] + (b - a) / st.noise_of(l)
                         if j > 0:
                             total[a:b] += coarser[a]
                 if want_var:

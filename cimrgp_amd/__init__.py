@@ -8,10 +8,11 @@ GPU, computing does.
 """
 from .IndexSetGenerator import IndexSetUniform
 from .KernelClass import RBFKernel, MaternKernel, LaplacianEigenpairs
+from .BasisInterval import BasisInterval
 from .RegressionInput import RegressionMethod, GP_RBF
 from .Posteriors import DensePosterior, DenseBlock
 from .MRGP import MultiResolutionGaussianProcess
 from . import _lib, device, dist
 
-__all__ = ["IndexSetUniform", "RBFKernel", "MaternKernel", "LaplacianEigenpairs", "RegressionMethod",
+__all__ = ["IndexSetUniform", "RBFKernel", "MaternKernel", "LaplacianEigenpairs", "BasisInterval", "RegressionMethod",
            "GP_RBF", "DensePosterior", "DenseBlock", "MultiResolutionGaussianProcess", "device", "dist"]

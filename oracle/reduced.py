@@ -109,7 +109,7 @@ def bingham_from_matrix(b):
     order = vals.argsort()[::-1]
     kappa = vals[order]
     axes = vecs[:, order]
-    log_c, rho = bingham_saddle(kappa)
+    log_c, rho = bingham_saddle(np.real(kappa))
     kappa = np.real(kappa).copy()
     kappa[kappa < 0] = 0.0
     return dict(kappa=kappa, axes=np.real(axes), rho=np.real(rho), log_const=float(np.real(log_c)))
@@ -195,6 +195,8 @@ class _Block:
         self.ard_log_mean = psi(self.ard_shape0) - np.log(self.ard_scale0)
         self.noise_shape, self.noise_scale = self.noise_shape0, self.noise_scale0
         self.noise_mean = self.noise_shape0 / self.noise_scale0
+        self.noise_log_mean = psi(self.noise_shape0) - np.log(self.noise_scale0)
+        self.y_var = 0.0
         self.bias_mean = np.zeros(dy)
         self.bias_prec = self.bias_prec0
         self.bias_var = 1.0 / self.bias_prec0
@@ -213,19 +215,17 @@ class _Block:
         self.zeta = self.noise_mean / self.precision
         self.ytil = y_tilde(y, self.phi, self.eau, self.bias_mean, self.fbar)
 
-    def bias_and_noise(self, y, y_var_term):
-        """Posteriors.py:345-372 (bias) then :396-412 (noise); note the noise residual does
-        not subtract the bias -- the bias enters through ``term4``."""
+    def residual_sums(self, y):
+        """The block sums the bias and noise updates share (Posteriors.py:345-372, 396-452):
+        sum and squared norm of  y - Phi E[au]^T - f_bar  (no bias), sum f_var, sum Phi^2 c2."""
         resid = y - self.phi @ self.eau.T - self.fbar
-        self.bias_prec = self.bias_prec0 + self.n
-        self.bias_mean = (0.0 * self.bias_prec0 + np.sum(resid, axis=0)) / self.bias_prec
-        dy = y.shape[1]
-        self.noise_shape = self.noise_shape0 + 0.5 * dy * self.n
-        term4 = self.bias_prec * np.dot(self.bias_mean, self.bias_mean)
-        self.noise_scale = self.noise_scale0 + 0.5 * (0.0 - term4 + np.sum(resid * resid) + np.sum(self.fvar)
-                                                      + np.sum(self.phi ** 2 * self.cen2) + y_var_term)
-        self.bias_var = 1.0 / self.bias_prec
-        self.noise_mean = self.noise_shape / self.noise_scale
+        return np.sum(resid, axis=0), np.sum(resid * resid), np.sum(self.fvar), np.sum(self.phi ** 2 * self.cen2)
+
+    def rebuild_basis(self, interval, spectral):
+        """MRGP.py:305-335 after an interval update."""
+        self.interval = np.asarray(interval, dtype=np.float64)
+        self.phi, self.lam = laplace_basis(self.x, self.interval, self.phi.shape[1])
+        self.spec = spectral(np.sqrt(self.lam))
 
     def contribution(self, phi=None):
         """bias + Phi E[au]^T and its variance (Stats.py:316-348)."""
@@ -235,11 +235,13 @@ class _Block:
 
 class ReducedRankModel:
     """fiMRGP (``forced_independence=True``) and ciMRGP (False) of the reference with its
-    default flags (region-specific noise and bias, fixed basis intervals, non-informative
-    priors, no input warping)."""
+    flag variants: region-specific or shared noise and bias, fixed or adaptive basis intervals,
+    SNR-initialised noise, the lower bound of ``fit(n_iter, tol)``; non-informative priors,
+    no input warping."""
 
     def __init__(self, x, y, bounds, n_basis, nu=1.0, ell=1.0, sf=1.0, forced_independence=True,
-                 interval_factor=1.0, snr_ratio=None):
+                 interval_factor=1.0, snr_ratio=None, noise_region_specific=True, bias_region_specific=True,
+                 adaptive_basis_intervals=False, opt_interval_factor=(1.0, 1.2)):
         x = np.asarray(x, dtype=np.float64)
         self.y = np.asarray(y, dtype=np.float64)
         self.mean_x = np.mean(x, 0)
@@ -251,7 +253,13 @@ class ReducedRankModel:
         self.dy = self.y.shape[1]
         self.fi = forced_independence
         self.n_layers = len(bounds)
+        self.noise_regional = noise_region_specific
+        self.bias_regional = bias_region_specific
+        self.adaptive = adaptive_basis_intervals and not forced_independence      # MRGP.py:110-111
+        self.opt_factor = opt_interval_factor
+        self.lower_bound, self.lower_bound_layer = [], [[] for _ in bounds]
         spectral = lambda s: matern_spectral(s, nu, ell, sf)
+        self.spectral = spectral
         noise_var0 = 1.0
         if snr_ratio is not None:                                      # MRGP.py:966-971, layer 0 only (:196-203)
             n0 = self.y.shape[0]
@@ -309,9 +317,53 @@ class ReducedRankModel:
                 blk.ard_scale = np.full(m, np.sum(blk.ard_scale0 / m)) + 0.5 * blk.mom2 / blk.spec
                 blk.ard_mean = blk.ard_shape / blk.ard_scale
             for blk in layer:
-                blk.bias_and_noise(blk.y, 0.0)
+                blk.y_var = 0.0
+            self._bias_and_noise(layer)
             if j + 1 < self.n_layers:
                 self._latent_for(j + 1)
+
+    def _bias_and_noise(self, layer):
+        """Bias (Posteriors.py:75-110 / 345-372) then noise (:113-211 / 375-452) of one layer for
+        the four region-specific / shared combinations.  The noise residual carries no bias --
+        the bias enters as  - precision |mean|^2.  Whether the target variance is multiplied by
+        the block size differs between the variants and between the two posterior classes
+        exactly as in the reference (only ciMRGP has a non-zero target variance)."""
+        sums = [blk.residual_sums(blk.y) for blk in layer]
+        dy = self.dy
+        if self.bias_regional:
+            for blk, sm in zip(layer, sums):
+                blk.bias_prec = blk.bias_prec0 + blk.n
+                blk.bias_mean = sm[0] / blk.bias_prec
+        else:
+            prec = layer[0].bias_prec0 + sum(blk.n for blk in layer)
+            mean = sum(sm[0] for sm in sums) / prec
+            for blk in layer:
+                blk.bias_prec, blk.bias_mean = prec, mean
+        both_regional = self.noise_regional and self.bias_regional
+        times_n = both_regional if self.fi else not both_regional
+        if self.fi and self.noise_regional and not self.bias_regional:
+            times_n = False                                             # Posteriors.py:420-422
+        terms = []
+        for blk, sm in zip(layer, sums):
+            y_var = blk.y_var * blk.n if times_n else blk.y_var
+            terms.append(sm[1] + sm[2] + sm[3] + y_var)
+        bias_term = [blk.bias_prec * np.dot(blk.bias_mean, blk.bias_mean) for blk in layer]
+        if self.noise_regional:
+            for blk, t, bt in zip(layer, terms, bias_term):
+                blk.noise_shape = blk.noise_shape0 + 0.5 * dy * blk.n
+                blk.noise_scale = blk.noise_scale0 + 0.5 * (0.0 - bt + t)
+        else:
+            shape = layer[0].noise_shape0 + sum(0.5 * dy * blk.n for blk in layer)
+            if self.bias_regional:
+                scale = layer[0].noise_scale0 + sum(0.5 * (0.0 - bt + t) for t, bt in zip(terms, bias_term))
+            else:
+                scale = layer[0].noise_scale0 + 0.5 * (0.0 - bias_term[0] + sum(terms))
+            for blk in layer:
+                blk.noise_shape, blk.noise_scale = shape, scale
+        for blk in layer:
+            blk.bias_var = 1.0 / blk.bias_prec
+            blk.noise_mean = blk.noise_shape / blk.noise_scale
+            blk.noise_log_mean = psi(blk.noise_shape) - np.log(blk.noise_scale)
 
     def sweep_shared(self):
         """MRGP.py:574-661 (ciMRGP): one Bingham axis and one ARD weight per basis function,
@@ -348,17 +400,122 @@ class ReducedRankModel:
             self.sh_ard_mean = self.sh['ard_shape'] / self.sh['ard_scale']
             self.sh_ard_log_mean = psi(self.sh['ard_shape']) - np.log(self.sh['ard_scale'])
             self.omega = soft_permutation(prev, self.sh_cov, self.sh_ard_log_mean, self.sh_ard_mean)
-            for blk in layer:
-                blk.bias_and_noise(blk.y, blk.y_var)                     # Posteriors.py:135 (no n factor)
+            self._bias_and_noise(layer)
+            if self.adaptive:                                            # MRGP.py:626-636
+                for blk in layer:
+                    blk.rebuild_basis(self._learn_interval(blk), self.spectral)
             if j + 1 < self.n_layers:
                 self._latent_for(j + 1)
 
-    def fit(self, n_iter):
-        for _ in range(n_iter):
+    def _learn_interval(self, blk):
+        """BasisInterval.py:18-54,64-92: per input dimension a bounded scalar minimisation
+        (scipy's ``fminbound``, as the reference) of ``_interval_objective`` between the data
+        range and 1.2x it (capped at n_basis), the other dimensions held at their old values."""
+        from scipy.optimize import fminbound
+        d = blk.x.shape[1]
+        m = self.m
+        orders = np.arange(1, m + 1)
+        per_dim = [np.sin(np.pi * orders[None, :] * (blk.x[:, [k]] + blk.interval[k]) / (2 * blk.interval[k]))
+                   / np.sqrt(blk.interval[k]) for k in range(d)]
+        lam_dim = [(np.pi * orders / (2 * blk.interval[k])) ** 2 for k in range(d)]
+        out = np.zeros(d)
+        for p in range(d):
+            if d > 1:
+                others = [k for k in range(d) if k != p]
+                penalty_phi = np.prod([per_dim[k] for k in others], axis=0)
+                penalty_lam = np.sum([lam_dim[k] for k in others], axis=0)
+            else:
+                penalty_phi = np.ones((blk.n, m))                       # MRGP.py:341-343: untouched when dx == 1
+                penalty_lam = np.zeros(m)
+            low = np.max(np.abs(blk.x[:, p])) * self.opt_factor[0]
+            high = min(m, low * self.opt_factor[1])
+            if high < low:
+                high = low * self.opt_factor[1]
+            out[p] = fminbound(self._interval_objective, low, high, args=(blk, p, penalty_phi, penalty_lam), full_output=0)
+        return out
+
+    def _interval_objective(self, interval, blk, p, penalty_phi, penalty_lam):
+        """BasisInterval.py:94-134, negated expected log-likelihood terms that depend on the
+        interval of dimension p plus the spectral prior term."""
+        m = self.m
+        orders = np.arange(1, m + 1)
+        xp = blk.x[:, [p]]
+        phi = np.sin(np.pi * orders[None, :] * (xp + interval) / (2 * interval)) / np.sqrt(interval)
+        lam = (np.pi * orders / (2 * interval)) ** 2
+        spec = self.spectral(np.sqrt(lam + penalty_lam))
+        psi_ = penalty_phi * phi
+        sq = np.sum(psi_ ** 2, axis=0)
+        term1 = np.sum(blk.eau ** 2, axis=0) * sq
+        term2 = np.einsum('nc,ci,ni->i', blk.bias_mean + blk.fbar, blk.eau, psi_)
+        term3 = np.einsum('nc,ci,ni->i', blk.y, blk.eau, psi_)
+        term4 = blk.cen2 * sq
+        ll = -0.5 * blk.noise_mean * np.sum(2 * term1 + 4 * term2 - 2 * term3 + term4)
+        prior = -0.5 * np.sum(np.log(spec) - 0.5 * (self.sh_ard_mean * blk.mom2) / spec)
+        return -(ll + prior)
+
+    # -- lower bound (MRGP.py:414-571) ----------------------------------------------------------
+    def _lower_bound(self):
+        """The quantity ``fit(n_iter, tol)`` monitors, term by term as the reference codes it --
+        including that the data term is the bare sum of squared-error and variance terms plus
+        the log-normaliser (no -E[tau]/2 factor), that the axis term multiplies the two matrices
+        elementwise before the trace, and that for j > 0 the "previous" shared posterior is the
+        current one (MRGP.py:379 aliases instead of copying)."""
+        m = self.m
+        per_layer = []
+        for j, layer in enumerate(self.blocks):
+            prev = self.sh_prior if j == 0 else self.sh
+            data = 0.0
+            const = 0.0
+            for blk in layer:
+                resid = blk.y - blk.phi @ blk.eau.T - blk.fbar - blk.bias_mean
+                data += np.sum(resid * resid) + np.sum(blk.fvar) + np.sum(blk.phi ** 2 * blk.cen2) + blk.bias_var \
+                    + blk.y_var * blk.n
+                const += 0.5 * self.dy * (blk.noise_log_mean - np.log(2 * np.pi)) * blk.n
+            data += const
+            scale = 0.0
+            for blk in layer:
+                scale += np.sum(0.5 * self.sh_ard_log_mean / blk.spec - 0.5 * self.sh_ard_mean * blk.mom2 / blk.spec)
+                scale -= np.sum(0.5 * np.log(blk.precision) - 0.5)
+            diag_cov = np.einsum('iaa->ia', self.sh_cov)
+            axis_p = np.sum(self.omega * (-prev['log_const'][None, :] + diag_cov @ np.einsum('kaa->ka', prev['b']).T))
+            axis_q = np.sum(-self.sh['log_const'] + np.sum(diag_cov * np.einsum('iaa->ia', self.sh['b']), axis=1))
+
+            def gamma_term(shape, scale_, log_mean, mean):
+                return shape * np.log(scale_) - gammaln(shape) + (shape - 1) * log_mean - scale_ * mean
+
+            ard_p = np.sum(self.omega * gamma_term(prev['ard_shape'][None, :], prev['ard_scale'][None, :],
+                                                   self.sh_ard_log_mean[:, None], self.sh_ard_mean[:, None]))
+            ard_q = np.sum(gamma_term(self.sh['ard_shape'], self.sh['ard_scale'], self.sh_ard_log_mean, self.sh_ard_mean))
+            bias = 0.0
+            noise = 0.0
+            for blk in layer:
+                w = blk.bias_mean
+                term = 1.0 / (blk.bias_prec * blk.noise_mean) + np.dot(w, w)
+                bias += 0.5 * self.dy * (np.log(blk.bias_prec0) + blk.noise_log_mean - np.log(2 * np.pi)) \
+                    + 0.5 * blk.bias_prec0 * blk.noise_mean * term
+                bias -= 0.5 * self.dy * (np.log(blk.bias_prec) + blk.noise_log_mean - np.log(2 * np.pi)) - 0.5
+                noise += gamma_term(blk.noise_shape0, blk.noise_scale0, blk.noise_log_mean, blk.noise_mean)
+                noise -= gamma_term(blk.noise_shape, blk.noise_scale, blk.noise_log_mean, blk.noise_mean)
+            per_layer.append(data + scale + (axis_p - axis_q) + (ard_p - ard_q) + bias + noise)
+        return float(np.sum(per_layer)), per_layer
+
+    def fit(self, n_iter, tol=None, min_iter=10):
+        """MRGP.py:367-412.  With ``tol`` the ciMRGP sweep also records the lower bound and stops
+        once, after ``min_iter`` sweeps, layer 0's bound changes by less than ``tol``."""
+        min_iter = min(min_iter, n_iter)
+        for it in range(1, n_iter + 1):
             if self.fi:
                 self.sweep_independent()
-            else:
-                self.sweep_shared()
+                continue
+            self.sweep_shared()
+            if tol is None:
+                continue
+            total, per_layer = self._lower_bound()
+            self.lower_bound.append(total)
+            for j, v in enumerate(per_layer):
+                self.lower_bound_layer[j].append(v)
+            if it > min_iter and abs(self.lower_bound_layer[0][-1] - self.lower_bound_layer[0][-2]) < abs(tol):
+                break
 
     # -- prediction -------------------------------------------------------------------------
     def _test_phi(self, xs_n, test_bounds):

@@ -190,6 +190,54 @@ def test_model_matches_oracle_2d_inputs(ca, forced):
     assert np.isfinite(ll)
 
 
+@pytest.mark.parametrize("tag", ["fi_r1_2d", "ci_r1_2d", "fi_r2_snr", "ci_r2_shared_nb", "ci_r2_shared_n", "ci_r2_shared_b",
+                                 "fi_r2_shared_nb", "ci_r2_bi", "ci_r1_bi_2d"])
+def test_model_flag_variants_match_reference_fit(ca, golden_dir, tag):
+    """2-D inputs, SNR-initialised noise, shared noise / bias and adaptive basis intervals (every
+    probe of the interval minimiser is a launch of the moments kernel) against the reference's
+    own fitted models."""
+    z = dict(np.load(os.path.join(golden_dir, "reference_model_%s.npz" % tag)))
+    kw = {}
+    for name in ("noise_region_specific", "bias_region_specific"):
+        if "kw_" + name in z:
+            kw[name] = bool(z["kw_" + name])
+    for name in ("snr_ratio", "interval_factor"):
+        if "kw_" + name in z:
+            kw[name] = float(z["kw_" + name])
+    if bool(z["adaptive_basis_intervals"]):
+        kw["basis_interval_obj"] = ca.BasisInterval(opt_interval_factor=(1, 1.2))
+    res = int(z["resolution"])
+    model = _build(ca, z["x"], z["y"], res, int(z["n_basis"]), bool(z["forced_independence"]), **kw)
+    model.fit(int(z["n_iter"]), None)
+    tol = 1e-7
+    for j in range(model.n_layers):
+        st = model.stats_obj[j]
+        for l in range(model.n_regions[j]):
+            key = "_%d_%d" % (j, l)
+            assert _rel(model.train_basis_intervals[j][l], z["interval" + key]) < tol
+            assert _rel(st.scale_axis_mean[l], z["scale_axis_mean" + key]) < tol
+            assert _rel(st.scale_moment2[l], z["scale_moment2" + key]) < tol
+        if not model.noise_region_specific:
+            assert abs(st.noise_mean - z["noise_mean_%d" % j]) < tol * abs(z["noise_mean_%d" % j])
+        if not model.bias_region_specific:
+            assert _rel(st.bias_mean, z["bias_mean_%d" % j]) < tol
+    idx_t = ca.IndexSetUniform(z["xt"].shape[0], res, 2)
+    assert _rel(model.get_predicted_mean(z["xt"]), z["pred_mean_global"]) < tol
+    assert _rel(model.get_central_moment2(z["xt"]), z["pred_var_global"]) < tol
+    assert _rel(model.get_predicted_mean(z["xt"], idx_t), z["pred_mean_index"]) < tol
+    assert _rel(model.get_central_moment2(z["xt"], idx_t), z["pred_var_index"]) < tol
+
+
+def test_lower_bound_matches_reference(ca, golden_dir):
+    z = dict(np.load(os.path.join(golden_dir, "reference_model_ci_r2_elbo.npz")))
+    model = _build(ca, z["x"], z["y"], 2, 30, False)
+    n_iter = int(z["n_iter"])
+    model.fit(n_iter, 1e-12, min_iter=n_iter)
+    got = np.array(model.lower_bound_layer)
+    assert np.max(np.abs(got - z["lower_bound_layer"]) / np.abs(z["lower_bound_layer"])) < 1e-8
+    assert np.max(np.abs(np.array(model.lower_bound) - z["lower_bound"]) / np.abs(z["lower_bound"])) < 1e-8
+
+
 def test_model_f32_close_to_f64(ca, golden_dir):
     z = np.load(os.path.join(golden_dir, "reference_model_fi_r2.npz"))
     model = _build(ca, z["x"], z["y"], 2, int(z["n_basis"]), True, dtype="f32")
@@ -198,7 +246,7 @@ def test_model_f32_close_to_f64(ca, golden_dir):
     assert _rel(model.get_predicted_mean(z["xt"], idx_t), z["pred_mean_index"]) < 5e-3
 
 
-def _two_rank_worker(rank, world, port, out_dir, forced):
+def _two_rank_worker(rank, world, port, out_dir, forced, tag=None):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch
@@ -206,11 +254,17 @@ def _two_rank_worker(rank, world, port, out_dir, forced):
     import cimrgp_amd as ca
     torch.cuda.set_device(0)
     td.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
-                             "reference_model_%s.npz" % ("fi_r3" if forced else "ci_r2")))
+    tag = tag or ("fi_r3" if forced else "ci_r2")
+    z = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_model_%s.npz" % tag)))
     res = int(z["resolution"])
-    model = _build(ca, z["x"], z["y"], res, int(z["n_basis"]), forced)
-    model.fit(5, None)
+    kw = {}
+    for name in ("noise_region_specific", "bias_region_specific"):
+        if "kw_" + name in z:
+            kw[name] = bool(z["kw_" + name])
+    if "adaptive_basis_intervals" in z and bool(z["adaptive_basis_intervals"]):
+        kw["basis_interval_obj"] = ca.BasisInterval(opt_interval_factor=(1, 1.2))
+    model = _build(ca, z["x"], z["y"], res, int(z["n_basis"]), forced, **kw)
+    model.fit(int(z["n_iter"]) if "n_iter" in z else 5, None)
     idx_t = ca.IndexSetUniform(z["xt"].shape[0], res, 2)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), mean=model.get_predicted_mean(z["xt"], idx_t),
              var=model.get_central_moment2(z["xt"], idx_t), glob=model.get_predicted_mean(z["xt"]),
@@ -218,8 +272,8 @@ def _two_rank_worker(rank, world, port, out_dir, forced):
     td.destroy_process_group()
 
 
-@pytest.mark.parametrize("forced", [True, False])
-def test_two_rank_sharded_reduced_model(ca, golden_dir, tmp_path, forced):
+@pytest.mark.parametrize("forced,tag", [(True, "fi_r3"), (False, "ci_r2"), (True, "fi_r2_shared_nb"), (False, "ci_r1_bi_2d")])
+def test_two_rank_sharded_reduced_model(ca, golden_dir, tmp_path, forced, tag):
     """Blocks sharded over 2 ranks (sharing the box's one GPU, gloo carrying the device tensors):
     per-layer latent-function reduce, shared-axis evidence reduce (ciMRGP), prediction reduce;
     both ranks must reproduce the reference's single-process fit."""
@@ -229,14 +283,13 @@ def test_two_rank_sharded_reduced_model(ca, golden_dir, tmp_path, forced):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), forced), nprocs=2, join=True)
-    tag = "fi_r3" if forced else "ci_r2"
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), forced, tag), nprocs=2, join=True)
     z = np.load(os.path.join(golden_dir, "reference_model_%s.npz" % tag))
     res = int(z["resolution"])
     last = "scale_axis_mean_%d_%d" % (res, 2 ** res - 1)
     for rank in range(2):
         g = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
-        assert _rel(g["mean"], z["pred_mean_index"]) < 1e-8
-        assert _rel(g["var"], z["pred_var_index"]) < 1e-8
-        assert _rel(g["glob"], z["pred_mean_global"]) < 1e-8
-        assert _rel(g["eau_last"], z[last]) < 1e-8           # host statistics synchronised to every rank
+        assert _rel(g["mean"], z["pred_mean_index"]) < 1e-7
+        assert _rel(g["var"], z["pred_var_index"]) < 1e-7
+        assert _rel(g["glob"], z["pred_mean_global"]) < 1e-7
+        assert _rel(g["eau_last"], z[last]) < 1e-7           # host statistics synchronised to every rank

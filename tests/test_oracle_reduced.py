@@ -52,6 +52,50 @@ def test_predictions_match_reference(golden_dir, tag):
     assert _rel(model.predict_var(z["xt"], tb), z["pred_var_index"]) < RTOL
 
 
+@pytest.mark.parametrize("tag", ["fi_r1_2d", "ci_r1_2d", "fi_r2_snr", "ci_r2_shared_nb", "ci_r2_shared_n", "ci_r2_shared_b",
+                                 "fi_r2_shared_nb", "ci_r2_bi", "ci_r1_bi_2d"])
+def test_flag_variants_match_reference(golden_dir, tag):
+    """2-D inputs, SNR-initialised noise, shared noise / bias, adaptive basis intervals."""
+    z = np.load(os.path.join(golden_dir, "reference_model_%s.npz" % tag))
+    res = int(z["resolution"])
+    kw = {}
+    for name in ("noise_region_specific", "bias_region_specific"):
+        if "kw_" + name in z.files:
+            kw[name] = bool(z["kw_" + name])
+    for name in ("snr_ratio", "interval_factor"):
+        if "kw_" + name in z.files:
+            kw[name] = float(z["kw_" + name])
+    kw["adaptive_basis_intervals"] = bool(z["adaptive_basis_intervals"])
+    model = ReducedRankModel(z["x"], z["y"], index_bounds_uniform(z["x"].shape[0], res, 2), int(z["n_basis"]),
+                             forced_independence=bool(z["forced_independence"]), **kw)
+    model.fit(int(z["n_iter"]))
+    tol = 1e-9 if "_bi" in tag else RTOL
+    for j, layer in enumerate(model.blocks):
+        for l, blk in enumerate(layer):
+            key = "_%d_%d" % (j, l)
+            assert _rel(blk.interval, z["interval" + key]) < tol
+            assert _rel(blk.eau, z["scale_axis_mean" + key]) < tol
+            assert _rel(blk.mom2, z["scale_moment2" + key]) < tol
+    if not model.fi:
+        assert _rel(model.omega, z["shared_omega"]) < 1e-7
+        assert _rel(model.sh_ard_mean, z["shared_ard_mean"]) < tol
+    tb = index_bounds_uniform(z["xt"].shape[0], res, 2)
+    assert _rel(model.predict_mean(z["xt"]), z["pred_mean_global"]) < tol
+    assert _rel(model.predict_var(z["xt"]), z["pred_var_global"]) < tol
+    assert _rel(model.predict_mean(z["xt"], tb), z["pred_mean_index"]) < tol
+    assert _rel(model.predict_var(z["xt"], tb), z["pred_var_index"]) < tol
+
+
+def test_lower_bound_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "reference_model_ci_r2_elbo.npz"))
+    model = ReducedRankModel(z["x"], z["y"], index_bounds_uniform(512, 2, 2), 30, forced_independence=False)
+    n_iter = int(z["n_iter"])
+    model.fit(n_iter, 1e-12, min_iter=n_iter)
+    got = np.array(model.lower_bound_layer)
+    assert np.max(np.abs(got - z["lower_bound_layer"]) / np.abs(z["lower_bound_layer"])) < 1e-10
+    assert np.max(np.abs(np.array(model.lower_bound) - z["lower_bound"]) / np.abs(z["lower_bound"])) < 1e-10
+
+
 def test_kernel_objects_match_reference(golden_dir):
     g = np.load(os.path.join(golden_dir, "kernel_objects.npz"))
     phi, lam = laplace_basis(g["lap_x2"], np.array([2.0, 1.7]), 7)

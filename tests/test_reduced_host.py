@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from cimrgp_amd import IndexSetUniform, LaplacianEigenpairs, MaternKernel
+from cimrgp_amd import BasisInterval, IndexSetUniform, LaplacianEigenpairs, MaternKernel
 from cimrgp_amd import device as dev
 from cimrgp_amd import ReducedRank as rr
 from cimrgp_amd.MRGP import MultiResolutionGaussianProcess
@@ -52,10 +52,28 @@ def numpy_device(monkeypatch):
             t = torch.as_tensor(v).to(var.dtype)
             var.copy_(var + t if accumulate else t)
 
+    def residual(y, fbar, bias, out=None):
+        return y - fbar - bias
+
+    monkeypatch.setattr(dev, "residual", residual)
     monkeypatch.setattr(dev, "require_gpu", lambda device=None: torch.device("cpu"))
     monkeypatch.setattr(dev, "laplace_basis", laplace_basis)
     monkeypatch.setattr(dev, "basis_moments", basis_moments)
     monkeypatch.setattr(dev, "basis_apply", basis_apply)
+
+
+def _kwargs_of(z):
+    """Constructor keywords recorded in a golden file (tests/golden/make_golden_reduced.py)."""
+    kw = {}
+    for name in ("noise_region_specific", "bias_region_specific"):
+        if "kw_" + name in z:
+            kw[name] = bool(z["kw_" + name])
+    for name in ("snr_ratio", "interval_factor"):
+        if "kw_" + name in z:
+            kw[name] = float(z["kw_" + name])
+    if "adaptive_basis_intervals" in z and bool(z["adaptive_basis_intervals"]):
+        kw["basis_interval_obj"] = BasisInterval(opt_interval_factor=(1, 1.2))
+    return kw
 
 
 def _build(z, **kw):
@@ -92,6 +110,56 @@ def test_host_model_matches_reference(golden_dir, numpy_device, tag):
     assert abs(np.sum(contrib[0][0]) - 1.0) < 1e-12
 
 
+@pytest.mark.parametrize("tag", ["fi_r1_2d", "ci_r1_2d", "fi_r2_snr", "ci_r2_shared_nb", "ci_r2_shared_n", "ci_r2_shared_b",
+                                 "fi_r2_shared_nb", "ci_r2_bi", "ci_r1_bi_2d"])
+def test_host_model_flag_variants_match_reference(golden_dir, numpy_device, tag):
+    """2-D inputs, SNR-initialised noise, shared noise / bias, adaptive basis intervals."""
+    z = dict(np.load(os.path.join(golden_dir, "reference_model_%s.npz" % tag)))
+    model = _build(z, **_kwargs_of(z))
+    model.fit(int(z["n_iter"]), None)
+    tol = 1e-8 if "_bi" in tag else RTOL            # the interval minimiser stops at xtol = 1e-5
+    for j in range(model.n_layers):
+        st = model.stats_obj[j]
+        for l in range(model.n_regions[j]):
+            key = "_%d_%d" % (j, l)
+            assert _rel(model.train_basis_intervals[j][l], z["interval" + key]) < tol
+            assert _rel(st.scale_axis_mean[l], z["scale_axis_mean" + key]) < tol
+            assert _rel(st.scale_moment2[l], z["scale_moment2" + key]) < tol
+            if model.bias_region_specific:
+                assert _rel(st.bias_mean[l], z["bias_mean" + key]) < tol
+            if model.noise_region_specific:
+                assert abs(st.noise_mean[l] - z["noise_mean" + key]) < tol * abs(z["noise_mean" + key])
+        if not model.noise_region_specific:
+            assert abs(st.noise_mean - z["noise_mean_%d" % j]) < tol * abs(z["noise_mean_%d" % j])
+        if not model.bias_region_specific:
+            assert _rel(st.bias_mean, z["bias_mean_%d" % j]) < tol
+    if not model.forced_independence:
+        assert _rel(model.shared_stats.omega, z["shared_omega"]) < 1e-7
+        assert _rel(model.shared_stats.ard_mean, z["shared_ard_mean"]) < tol
+    idx_t = IndexSetUniform(z["xt"].shape[0], int(z["resolution"]), 2)
+    assert _rel(model.get_predicted_mean(z["xt"]), z["pred_mean_global"]) < tol
+    assert _rel(model.get_central_moment2(z["xt"]), z["pred_var_global"]) < tol
+    assert _rel(model.get_predicted_mean(z["xt"], idx_t), z["pred_mean_index"]) < tol
+    assert _rel(model.get_central_moment2(z["xt"], idx_t), z["pred_var_index"]) < tol
+
+
+def test_host_lower_bound_matches_reference(golden_dir, numpy_device):
+    """fit(n_iter, tol): the recorded bound per sweep and per layer (MRGP.py:374-398,414-571)."""
+    z = dict(np.load(os.path.join(golden_dir, "reference_model_ci_r2_elbo.npz")))
+    model = _build(z)
+    n_iter = int(z["n_iter"])
+    model.fit(n_iter, 1e-12, min_iter=n_iter)
+    assert len(model.lower_bound) == n_iter
+    got = np.array(model.lower_bound_layer)
+    assert got.shape == z["lower_bound_layer"].shape
+    assert np.max(np.abs(got - z["lower_bound_layer"]) / np.abs(z["lower_bound_layer"])) < 1e-9
+    assert np.max(np.abs(np.array(model.lower_bound) - z["lower_bound"]) / np.abs(z["lower_bound"])) < 1e-9
+    # early stop: a loose tolerance ends the loop right after min_iter
+    model2 = _build(z)
+    model2.fit(n_iter, 1e60, min_iter=2)
+    assert len(model2.lower_bound) == 3
+
+
 def test_bingham_normaliser_matches_brent(golden_dir):
     """The vectorised Newton solve against scipy's Brent on the same equation."""
     from scipy.optimize import brentq
@@ -113,7 +181,7 @@ def test_bingham_normaliser_matches_brent(golden_dir):
 def test_unsupported_configurations_raise(numpy_device, golden_dir):
     z = np.load(os.path.join(golden_dir, "reference_model_fi_r2.npz"))
     with pytest.raises(TypeError):
-        _build(z, noise_region_specific=False)
+        _build(z, noise_region_specific=None)
     with pytest.raises(TypeError):
         _build(dict(z, forced_independence=np.bool_(False)), axis_resolution_specific=True)
     with pytest.raises(ValueError):
