@@ -293,3 +293,18 @@ def test_two_rank_sharded_reduced_model(ca, golden_dir, tmp_path, forced, tag):
         assert _rel(g["var"], z["pred_var_index"]) < 1e-7
         assert _rel(g["glob"], z["pred_mean_global"]) < 1e-7
         assert _rel(g["eau_last"], z[last]) < 1e-7           # host statistics synchronised to every rank
+
+
+def test_reference_example_recipe(ca):
+    """scripts/tests/ciMRGP_vs_fiMRGP.py's configuration end to end: learned input warp (exact RBF
+    GP on the GPU), adaptive basis intervals, index-set mean, global variance."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "cimrgp_vs_fimrgp.py")
+    spec = importlib.util.spec_from_file_location("cimrgp_example", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    train, test = mod.generate_data(n_test=20000)
+    for forced in (False, True):
+        out = mod.run(train, test, n_res=1, divider=2, n_basis=15, n_iter=10, forced_independence=forced)
+        assert np.isfinite(out["mll"]) and np.isfinite(out["mse"])
+        assert out["r2"] > 0.5, out
