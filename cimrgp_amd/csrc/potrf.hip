@@ -703,7 +703,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     const bool rows = (b != nullptr && m > 0);
     CIMRGP_HIP_TRY(hipMemsetAsync(info, 0, sizeof(int32_t), st), "hipMemsetAsync(info)");
     const int64_t npanels = (n + CIMRGP_NB - 1) / CIMRGP_NB;
-    LookAhead* la = (npanels > 2) ? lookahead_ctx((size_t)(3 * npanels + 4)) : nullptr;
+    LookAhead* la = (npanels > 2) ? lookahead_ctx((size_t)(4 * npanels + 8)) : nullptr;
     if (la == nullptr) {
         int rc0 = panel_sweep<T, true>(k, n, ld, ws, info, b, m, ldb, st);
         return rc0 ? rc0 : build_invT<T>(k, n, ld, ws, st);
@@ -711,23 +711,28 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
 
     hipStream_t sp = la->side;
     size_t ne = 0;
-    // The caller's stream does the "head" update, the trailing update and -- off the panel
-    // chain -- the carried rows' panel solve + update; the side stream does the latency-bound
-    // panel chain.  (Reserving CUs for the chain with a CU-masked bulk stream was measured and
-    // rejected: a masked queue ran the trailing update 20 % slower even with 8 of 256 CUs masked.)
-    int rc = factor_panel<T>(k, n, ld, ws, info, 0, (n < CIMRGP_NB) ? n : CIMRGP_NB, st);
+    // The side stream runs the whole latency-bound chain in stream order -- "head" update of the
+    // next panel's columns, then that panel's factorisation -- so that no inter-queue signal
+    // sits between two links of the chain; the caller's stream runs the bulk of each trailing
+    // update (and, off the chain, the carried rows).  Cross-stream edges: "panel final"
+    // (side -> main, before the bulk update that reads it) and "bulk update done" (main -> side,
+    // before the next head touches columns the bulk update wrote).
+    // (Reserving CUs for the chain with a CU-masked bulk stream was measured and rejected: a
+    // masked queue ran the trailing update 20 % slower even with 8 of 256 CUs masked.)
+    hipEvent_t ev_start = la->ev[ne++];
+    CIMRGP_HIP_TRY(hipEventRecord(ev_start, st), "hipEventRecord");
+    CIMRGP_HIP_TRY(hipStreamWaitEvent(sp, ev_start, 0), "hipStreamWaitEvent");
+    int rc = factor_panel<T>(k, n, ld, ws, info, 0, (n < CIMRGP_NB) ? n : CIMRGP_NB, sp);
     if (rc) return rc;
-    bool side_pending = false;
-    hipEvent_t ev_panel = nullptr;
+    hipEvent_t ev_panel = la->ev[ne++];
+    CIMRGP_HIP_TRY(hipEventRecord(ev_panel, sp), "hipEventRecord");
+    hipEvent_t ev_rest = nullptr;                      // bulk update of the previous panel
     int64_t rows_next = 0;                             // first panel the carried rows have not seen yet
     for (int64_t k0 = 0; k0 < n; k0 += CIMRGP_NB) {
         const int64_t w  = (n - k0 < CIMRGP_NB) ? (n - k0) : CIMRGP_NB;
         const int64_t k1 = k0 + w;
-        if (side_pending) {                            // panel k0 was factored on the side stream
-            CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0), "hipStreamWaitEvent");
-            side_pending = false;
-        }
-        hipEvent_t ev_final = nullptr;                 // "panel k0 is final", for the carried rows' queue
+        CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0), "hipStreamWaitEvent");   // panel k0 is final
+        hipEvent_t ev_final = nullptr;                 // the same fact, for the carried rows' queue
         if (rows && la->rows) {
             ev_final = la->ev[ne++];
             CIMRGP_HIP_TRY(hipEventRecord(ev_final, st), "hipEventRecord");
@@ -735,20 +740,17 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
         if (k1 < n) {
             const int64_t wn = (n - k1 < CIMRGP_NB) ? (n - k1) : CIMRGP_NB;   // next panel
             const int64_t k2 = k1 + wn;
-            // head: columns of the next panel, all rows below
+            // chain: head (columns of the next panel, all rows below), then the next panel
+            if (ev_rest) CIMRGP_HIP_TRY(hipStreamWaitEvent(sp, ev_rest, 0), "hipStreamWaitEvent");
             rc = gemm_nt_sub<T>(k + k1 * ld + k1, ld, k + k1 * ld + k0, ld, k + k1 * ld + k0, ld,
-                                n - k1, wn, (int)w, false, st);
+                                n - k1, wn, (int)w, false, sp);
             if (rc) return rc;
-            hipEvent_t ev_head = la->ev[ne++];
-            CIMRGP_HIP_TRY(hipEventRecord(ev_head, st), "hipEventRecord");
-            // next panel on the side stream, concurrently with the rest of this update
-            CIMRGP_HIP_TRY(hipStreamWaitEvent(sp, ev_head, 0), "hipStreamWaitEvent");
             rc = factor_panel<T>(k, n, ld, ws, info, k1, wn, sp);
             if (rc) return rc;
             ev_panel = la->ev[ne++];
             CIMRGP_HIP_TRY(hipEventRecord(ev_panel, sp), "hipEventRecord");
-            side_pending = true;
-            // rest: lower SYRK beyond the next panel
+            // bulk: lower SYRK beyond the next panel, concurrently with the chain
+            ev_rest = nullptr;
             if (n > k2) {
                 const double mm = (double)(n - k2);
                 TrailRec* rec = rec_open(st, mm * (mm + 1.0) * (double)w);
@@ -756,6 +758,8 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
                                     n - k2, n - k2, (int)w, true, st);
                 if (rec) (void)hipEventRecord(rec->stop, st);
                 if (rc) return rc;
+                ev_rest = la->ev[ne++];
+                CIMRGP_HIP_TRY(hipEventRecord(ev_rest, st), "hipEventRecord");
             }
         }
         if (rows) {
@@ -790,7 +794,6 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
         CIMRGP_HIP_TRY(hipEventRecord(ev_rows_done, la->rows), "hipEventRecord");
         CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_rows_done, 0), "hipStreamWaitEvent");
     }
-    if (side_pending) CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0), "hipStreamWaitEvent");
     return build_invT<T>(k, n, ld, ws, st);
 }
 

@@ -1,0 +1,20 @@
+"""One warmed-up potrf at size n (default 8192) for kernel-trace timelines:
+   rocprofv3 --kernel-trace -d gpurun_out/trace -- python3 tools/potrf_once.py [n] [reps]"""
+import sys
+
+import numpy as np
+import torch
+
+from cimrgp_amd import device as dev
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+dev.require_gpu()
+rng = np.random.default_rng(0)
+x = torch.as_tensor(np.sort(rng.uniform(-1.7, 1.7, size=(n, 1)), axis=0)).cuda()
+for _ in range(reps):
+    k = dev.rbf_gram(x, 0.1, 1.0, 0.01, lower_only=True)
+    torch.cuda.synchronize()
+    dev.potrf(k, n)
+    torch.cuda.synchronize()
+print("done")
