@@ -25,8 +25,10 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 #ifdef CIMRGP_STAMP   // diagnostic builds only (tools/diag_probe.hip): phase stamps of workgroup 0
 __device__ long long g_stamp[32];
 #define STAMP(n) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_stamp[n] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMPW(n, wv) do { if (threadIdx.x == 64 * (wv) && blockIdx.x == 0) g_stamp[n] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(n) do { } while (0)
+#define STAMPW(n, wv) do { } while (0)
 #endif
 
 // ------------------------------------------------------------ MFMA traits ----

@@ -221,12 +221,10 @@ template <> __device__ __forceinline__ float rsqrt_refined<float>(float d)
 //   S = A_ss - Lrow Lrow^T        Lrow = the kprev panel columns left of the
 //                                 block, already final (MFMA, K = kprev <= 192)
 //   S = L L^T  in place, inv slab = L^-1 (lower; zero elsewhere).
-// Factor and inverse advance together, one barrier per column.  Thread
-// (i = tid & 63, g = tid >> 6) keeps row i, columns k = g + 4u (u < 16) of the
-// unscaled Schur complement S and of the unscaled inverse Mi in REGISTERS; per
-// column only column j of S and row j of Mi travel through LDS (double
-// buffered).  Column j of L is S[:,j] r_j and row j of L^-1 is Mi[j,:] r_j,
-// r_j = 1/sqrt(S[j][j]); the row operations that reduce S are applied to Mi.
+// Factor and inverse advance together on the unscaled Schur complement S and the
+// unscaled inverse Mi: column j of L is S[:,j] r_j and row j of L^-1 is
+// Mi[j,:] r_j, r_j = 1/sqrt(S[j][j]); the row operations that reduce S are
+// applied to Mi.
 // ---------------------------------------------------------------------------
 // LDS-only barrier: waits for this wave's LDS traffic, not for global stores in
 // flight (a plain __syncthreads() also drains vmcnt, i.e. every store's round trip).
@@ -235,22 +233,45 @@ static __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// Register layout of the column loop: thread (i = tid & 63, g = tid >> 6) keeps row i,
-// columns k = 16 g + u (u < 16) of ONE combined 64x64 array A:
+// S and Mi are held as ONE combined 64x64 array A:
 //     A[i][k] = S[i][k]   for k <= i   (Schur complement, lower triangle)
 //     A[i][k] = Mi[k][i]  for k >  i   (unscaled inverse, stored transposed in the upper triangle)
-// At pivot j everything a thread needs is column j of A: A[i][j] is S[i][j] for i >= j and
-// Mi[j][i] for i < j, so the wave that owns column j publishes it with ONE LDS store, and
+// At pivot j everything needed is column j of A: A[i][j] is S[i][j] for i >= j and
+// Mi[j][i] for i < j, and
 //     A[i][k] -= (A[k][j] r) * h_i   for every k > j,    r = 1/sqrt(A[j][j]),
 //     h_i = L[i][j] = A[i][j] r (i > j),  L^-1[j][i] = A[i][j] r (i < j),  r (i = j, from 0)
 // covers the Schur update, the inverse update and the birth of column j of Mi in one
 // formula (for j < i < k it touches a not-yet-born Mi slot, which is reset at pivot i).
-// Waves left of the pivot column have nothing to do; register indices are compile-time
-// constants (u0 unrolled, wave index looped).
-constexpr int DG_NW = 8;              // waves of the diagonal kernel: two per SIMD (the loop is VALU-issue bound)
-constexpr int DG_NS = SB / DG_NW;     // register slots (columns) per lane
+constexpr int DG_TW = 8;              // tile waves of the diagonal kernel (two 16x16 tiles each)
+constexpr int DG_NW = DG_TW + 1;      // + the pivot wave
 constexpr int DG_NT = 64 * DG_NW;
 
+// One 16x16x4 matrix-core step (K = 4 = the pivots of one block).
+static __device__ __forceinline__ Mx<double>::acc_t mfma_k4(double a, double b, Mx<double>::acc_t c)
+{
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+static __device__ __forceinline__ Mx<float>::acc_t mfma_k4(float a, float b, Mx<float>::acc_t c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// Version 3 of the diagonal kernel.  The combined array A (see above) lives in MATRIX-CORE
+// ACCUMULATOR layout in eight "tile" waves: wave g < 8 owns the two 16x16 tiles (row tile g >> 1,
+// column tiles 2 (g & 1) + {0, 1}).  A ninth wave, the pivot wave, works in "lane = row" layout
+// on four columns at a time.  Per block p of BC = 4 pivots, ONE barrier:
+//   pivot wave   takes block p's columns (gathered by the tile waves one iteration earlier, i.e.
+//                updated through block p-2), applies block p-1's rank-4 update to them itself
+//                (16 FMAs per lane, coefficients by v_readlane from its own registers), eliminates
+//                the 4 pivots among themselves (wave-local broadcasts, 4 dependent rsqrt/scale
+//                steps) and publishes the rank-4 update's two operands (64 x 4 each);
+//   tile waves   meanwhile apply block p-1's update to their tiles with one matrix-core
+//                instruction per tile, then gather block p+1's columns for the pivot wave.
+// The pivot-time columns, kept for all 64 pivots, and the 64 reciprocal roots ARE the result:
+// L[i][j] = cs[i][j] r_j (i >= j), L^-1[j][i] = cs[i][j] r_j (i < j), L^-1[j][j] = r_j.
+// (Version 1 kept A in "lane = row" registers in all waves and applied the rank-4 update with
+// scalar FMAs whose per-column coefficients every wave read as LDS broadcasts: 2 MB of LDS
+// return traffic per block, 1.1 us per 4 pivots of which the pivots themselves were 0.24 us.)
 template <typename T>
 __global__ __launch_bounds__(DG_NT)
 void k_diag64(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow, int kprev,
@@ -259,137 +280,172 @@ void k_diag64(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow, 
     using X = Mx<T>;
     using TL = Tile64<T>;
     using acc_t = typename X::acc_t;
-    constexpr int LS = SB + 1;
-    __shared__ __attribute__((aligned(16))) unsigned char chunk[TL::BYTES];   // Lrow chunk, later L^-1 out
-    __shared__ T S[SB * LS];                                                  // Schur block, later L out
-    constexpr int BC = 4;                                                     // pivots per barrier
-    __shared__ __attribute__((aligned(16))) T comb4[2][SB][BC];               // BC pivot-time columns of A
+    constexpr int LS = SB + 2;       // even pitch: a row's 4 block columns are one 16-byte-aligned pair of stores
+    constexpr int BC = 4;
+    constexpr int NP = SB / BC;
+    constexpr int TT = 64 * DG_TW;                                            // threads of the tile waves
+    static_assert(DG_TW == 8 && DG_NW == 9, "tile ownership below assumes 8 tile waves + 1 pivot wave");
+    __shared__ __attribute__((aligned(16))) unsigned char chunk[TL::BYTES];   // Lrow chunk of the prologue
+    __shared__ __attribute__((aligned(16))) T pcol[2][SB][BC];                // gathered pivot columns, double buffered
+    __shared__ __attribute__((aligned(16))) T hs[2][SB][BC];                  // left operand (per row), double buffered
+    __shared__ __attribute__((aligned(16))) T cs[SB * LS];                    // right operand = pivot-time columns, kept
+    __shared__ T rall[SB];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int i = tid & 63;
+    const int i = lane;
     const int g = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave id: provably uniform
+    const bool tile_wave = g < DG_TW;
+    const int br = (g >> 1) & 3, ch = g & 1;
+    const int fcol = lane & 15, fk = lane >> 4;
     // latency-bound chain running next to MFMA-bound update workgroups: win issue arbitration
     __builtin_amdgcn_s_setprio(3);
 
     STAMP(0);
-    for (int e = tid; e < SB * SB; e += DG_NT) {
-        const int r = e >> 6, c = e & 63;
-        T v = (r == c) ? (T)1 : (T)0;
-        if (r < w && c <= r) v = D[(int64_t)r * ld + c];
-        S[r * LS + c] = v;
+    // S = A_ss - Lrow Lrow^T, straight into the accumulator layout
+    acc_t pacc[2];
+    pacc[0] = acc_zero<T>();
+    pacc[1] = acc_zero<T>();
+    if (kprev > 0) {
+        // kprev <= 192: all (up to three) 64-column chunks of Lrow are requested at once, so only
+        // one global round trip is exposed; each then goes registers -> LDS -> matrix cores
+        constexpr int NR = SB * TL::CPR / TT;         // 16-byte pieces per thread and chunk
+        constexpr int MAXC = (CIMRGP_NB - SB) / SB;
+        uint4 regs[MAXC][NR];
+        if (tile_wave) {
+#pragma unroll
+            for (int q = 0; q < MAXC; ++q) {
+                if (q * SB < kprev) {
+#pragma unroll
+                    for (int p = 0; p < NR; ++p) {
+                        const int e = tid + TT * p, r = e / TL::CPR, c = e - r * TL::CPR;
+                        regs[q][p] = (r < w) ? *reinterpret_cast<const uint4*>(Lrow + q * SB + (int64_t)r * ld + c * X::EPC)
+                                             : make_uint4(0, 0, 0, 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < MAXC; ++q) {
+            if (q * SB < kprev) {                      // uniform
+                if (q) __syncthreads();                // the previous chunk has been consumed
+                if (tile_wave) {
+#pragma unroll
+                    for (int p = 0; p < NR; ++p) {
+                        const int e = tid + TT * p, r = e / TL::CPR, c = e - r * TL::CPR;
+                        *reinterpret_cast<uint4*>(chunk + r * TL::LROW + c * 16) = regs[q][p];
+                    }
+                }
+                __syncthreads();
+                if (tile_wave) mma_chunk32<T, false>(pacc, chunk, chunk, br, ch, lane);
+            }
+        }
     }
     STAMP(1);
-    if (kprev > 0) {
-        acc_t acc[4];
+    acc_t acc[2];
+    acc[0] = acc_zero<T>();
+    acc[1] = acc_zero<T>();
+    if (tile_wave) {
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[ct] = acc_zero<T>();
-        // chunk kc+1 travels global -> registers while chunk kc is multiplied
-        constexpr int NR = SB * TL::CPR / DG_NT;      // 16-byte pieces per thread and chunk
-        uint4 regs[NR];
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int p = 0; p < NR; ++p) {
-            const int e = tid + DG_NT * p, r = e / TL::CPR, c = e - r * TL::CPR;
-            regs[p] = (r < w) ? *reinterpret_cast<const uint4*>(Lrow + (int64_t)r * ld + c * X::EPC) : make_uint4(0, 0, 0, 0);
-        }
-        for (int kc = 0; kc < kprev; kc += SB) {
-            __syncthreads();
-#pragma unroll
-            for (int p = 0; p < NR; ++p) {
-                const int e = tid + DG_NT * p, r = e / TL::CPR, c = e - r * TL::CPR;
-                *reinterpret_cast<uint4*>(chunk + r * TL::LROW + c * 16) = regs[p];
+            for (int r = 0; r < 4; ++r) {
+                const int row = br * 16 + X::crow(lane, r), col = (2 * ch + c) * 16 + fcol;
+                T v = (row == col) ? (T)1 : (T)0;                   // identity padding; strict upper part is zero
+                if (row < w && col <= row) v = D[(int64_t)row * ld + col] - pacc[c][r];
+                acc[c][r] = v;
             }
-            __syncthreads();
-            if (kc + SB < kprev) {
+        // blocks 0 and 1 for the pivot wave (both in tile column 0)
+        if (ch == 0 && fcol < 2 * BC) {
 #pragma unroll
-                for (int p = 0; p < NR; ++p) {
-                    const int e = tid + DG_NT * p, r = e / TL::CPR, c = e - r * TL::CPR;
-                    regs[p] = (r < w) ? *reinterpret_cast<const uint4*>(Lrow + kc + SB + (int64_t)r * ld + c * X::EPC)
-                                      : make_uint4(0, 0, 0, 0);
-                }
-            }
-            if (g < 4) mma_chunk64<T, false>(acc, chunk, chunk, g, lane);
-        }
-        if (g < 4) {
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = g * 16 + X::crow(lane, r), col = ct * 16 + (lane & 15);
-                    if (row < w && col <= row) S[row * LS + col] -= acc[ct][r];
-                }
+            for (int r = 0; r < 4; ++r) pcol[fcol / BC][br * 16 + X::crow(lane, r)][fcol % BC] = acc[0][r];
         }
     }
-    __syncthreads();
-
-    T a[DG_NS];
-#pragma unroll
-    for (int u = 0; u < DG_NS; ++u) a[u] = S[i * LS + DG_NS * g + u];   // strict upper part of S is zero
-    T* lout = S;                                   // L[i][j]    at lout[i * LS + j]
-    T* iout = reinterpret_cast<T*>(chunk);         // L^-1[j][c] at iout[j * SB + c]
-    __syncthreads();
-    for (int e = tid; e < SB * SB; e += DG_NT) iout[e] = (T)0;
+    lds_barrier();
     STAMP(2);
 
-    // Column loop, BC pivots per barrier.  The wave that owns columns j0..j0+BC-1 (same register
-    // slots u0..u0+BC-1 of every lane) eliminates them among themselves with wave-local broadcasts
-    // (v_readlane, no LDS, no barrier), publishes the BC pivot-time columns with 16-byte LDS
-    // stores, and after ONE barrier every wave applies the rank-BC update to its
-    // slots right of the block.  A lane that is itself a pivot row of the block (i = j0 + p)
-    // starts its not-yet-born inverse entries from 0 and takes contributions from pivots >= p only.
-    for (int gg = 0; gg < DG_NW; ++gg) {
+    T cv[BC], rr[BC], hsr[BC];                     // pivot wave: this row's block columns, roots, left operand
 #pragma unroll
-        for (int ub = 0; ub < DG_NS / BC; ++ub) {
-            const int u0 = BC * ub;
-            const int j0 = DG_NS * gg + u0;
-            T (*cb)[BC] = comb4[(j0 / BC) & 1];
-            T colv[BC], rr[BC];
-            if (g == gg) {
+    for (int t = 0; t < BC; ++t) { cv[t] = (T)0; rr[t] = (T)1; hsr[t] = (T)0; }
+
+    for (int p = 0; p < NP; ++p) {
+        const int j0 = BC * p, bc0 = j0 >> 4, jb = j0 & 15;
+        if (!tile_wave) {
+            // ---- pivot wave: dependent FP64 ops and nothing else
+            // this row's share of block p as gathered (two 16-byte reads, in flight during the FMAs below)
+            const T* gp = &pcol[p & 1][i][0];
+            T nx[BC];
 #pragma unroll
-                for (int t = 0; t < BC; ++t) {
-                    const int j = j0 + t;
-                    colv[t] = a[u0 + t];
-                    const T d = bcast_lane(colv[t], j);
-                    const T r = rsqrt_refined<T>(d);
-                    rr[t] = r;
-                    const T h = (i == j) ? r : colv[t] * r;
-                    const T nhr = -h * r;
+            for (int t = 0; t < BC; ++t) nx[t] = gp[t];
+            if (p > 0) {
+                // block p-1's update of block p's columns (the tile waves have not applied it to
+                // what was gathered); rows of block p-1 restart from 0
+                const bool prev_rows = (i >= j0 - BC) && (i < j0);
 #pragma unroll
-                    for (int t2 = t + 1; t2 < BC; ++t2) {
-                        const T ak = bcast_lane(colv[t], j0 + t2);          // A[k][j] at pivot time
-                        a[u0 + t2] = fma(nhr, ak, (i == j) ? (T)0 : a[u0 + t2]);
-                    }
-                    if (!(d > (T)0) && i == j && j < w) atomicCAS(info, 0, col_base + j + 1);
-                    if (i >= j) lout[i * LS + j] = (i == j) ? d * r : h;
-                    else        iout[j * SB + i] = h;
-                    if (i == j) iout[j * SB + j] = r;
+                for (int t2 = 0; t2 < BC; ++t2) {
+                    T u = hsr[0] * bcast_lane(cv[0], j0 + t2);
+#pragma unroll
+                    for (int t = 1; t < BC; ++t) u = fma(hsr[t], bcast_lane(cv[t], j0 + t2), u);
+                    nx[t2] = prev_rows ? u : nx[t2] + u;
                 }
-#pragma unroll
-                for (int t = 0; t < BC; ++t) cb[i][t] = colv[t];
             }
+#pragma unroll
+            for (int t = 0; t < BC; ++t) cv[t] = nx[t];
+            int bad = 0;                                                 // 1 + first non-positive pivot of the block
+            const bool in_block = (i >= j0) && (i < j0 + BC);
+#pragma unroll
+            for (int t = 0; t < BC; ++t) {
+                const int j = j0 + t;
+                const T d = bcast_lane(cv[t], j);
+                const T r = rsqrt_refined<T>(d);
+                rr[t] = r;
+                const T h = (i == j) ? r : cv[t] * r;
+                const T nhr = -h * r;
+#pragma unroll
+                for (int t2 = t + 1; t2 < BC; ++t2) {
+                    const T ak = bcast_lane(cv[t], j0 + t2);                // A[k][j] at pivot time
+                    cv[t2] = fma(nhr, ak, (i == j) ? (T)0 : cv[t2]);
+                }
+                if (!(d > (T)0) && bad == 0 && j < w) bad = j + 1;          // uniform: d is a broadcast value
+                hsr[t] = (in_block && i > j) ? (T)0 : nhr;
+            }
+            T* hp = &hs[p & 1][i][0];
+            T* cp = &cs[i * LS + j0];
+#pragma unroll
+            for (int t = 0; t < BC; ++t) {
+                hp[t] = hsr[t];
+                cp[t] = cv[t];
+            }
+            if (i < BC) rall[j0 + i] = (i == 0) ? rr[0] : (i == 1) ? rr[1] : (i == 2) ? rr[2] : rr[3];
             lds_barrier();
-            if (g >= gg) {
-                if (g != gg) {
+            if (bad != 0 && lane == 0) atomicCAS(info, 0, col_base + bad);
+        } else {
+            lds_barrier();
+            // ---- tile waves: block p's rank-4 update of every tile right of (or containing the
+            // rest of) the block, then the gather of block p+2 (updated through block p)
 #pragma unroll
-                    for (int t = 0; t < BC; ++t) {
-                        colv[t] = cb[i][t];
-                        rr[t] = rsqrt_refined<T>(cb[j0 + t][t]);
+            for (int c = 0; c < 2; ++c) {
+                const int bc = 2 * ch + c;
+                if (bc >= bc0) {
+                    const int col = bc * 16 + fcol;
+                    if (br == bc0) {                              // rows of the block: their slots right of it restart from 0
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int rin = X::crow(lane, r);
+                            if (rin >= jb && rin < jb + BC && col >= j0 + BC) acc[c][r] = (T)0;
+                        }
                     }
+                    const T af = hs[p & 1][br * 16 + fcol][fk];
+                    T bf = cs[(bc * 16 + fcol) * LS + j0 + fk];
+                    if (col < j0 + BC) bf = (T)0;                 // columns of the block and left of it are final
+                    acc[c] = mfma_k4(af, bf, acc[c]);
                 }
-                const bool in_block = (i >= j0) && (i < j0 + BC);
-                T nhr[BC];
+            }
+            if (p + 2 < NP) {
+                const int g0 = j0 + 2 * BC, gbc = g0 >> 4, gjb = g0 & 15;     // block p+2
+                if (ch == (gbc >> 1) && fcol >= gjb && fcol < gjb + BC) {
+                    const int c = gbc & 1;
 #pragma unroll
-                for (int t = 0; t < BC; ++t) {
-                    const T h = (i == j0 + t) ? rr[t] : colv[t] * rr[t];
-                    nhr[t] = (in_block && i > j0 + t) ? (T)0 : -h * rr[t];
-                }
-#pragma unroll
-                for (int u = 0; u < DG_NS; ++u) {
-                    if (g > gg || u >= u0 + BC) {               // columns right of the block
-                        const int k = DG_NS * g + u;
-                        T v = in_block ? (T)0 : a[u];
-#pragma unroll
-                        for (int t = 0; t < BC; ++t) v = fma(nhr[t], cb[k][t], v);
-                        a[u] = v;
-                    }
+                    for (int r = 0; r < 4; ++r)
+                        pcol[p & 1][br * 16 + X::crow(lane, r)][fcol - gjb] = (c == 0) ? acc[0][r] : acc[1][r];
                 }
             }
         }
@@ -398,8 +454,11 @@ void k_diag64(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow, 
     __syncthreads();
     for (int e = tid; e < SB * SB; e += DG_NT) {
         const int r = e >> 6, c = e & 63;
-        if (r < w && c <= r) D[(int64_t)r * ld + c] = lout[r * LS + c];
-        inv[e] = (r < w && c < w) ? iout[e] : (T)0;
+        if (r < w && c <= r) D[(int64_t)r * ld + c] = cs[r * LS + c] * rall[c];
+        T v = (T)0;
+        if (r < w && c < r) v = cs[c * LS + r] * rall[r];
+        if (r < w && c == r) v = rall[r];
+        inv[e] = v;
     }
     STAMP(4);
 }

@@ -36,6 +36,7 @@ int main()
             hipLaunchKernelGGL((k_diag64<double>), dim3(1), dim3(DG_NT), 0, 0, dK + (size_t)256 * ld + 256, (int64_t)ld, 64, dK + (size_t)256 * ld + 256 - kprev, kprev, dws, dinfo, 0);
             hipDeviceSynchronize();
             hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamp), sizeof(st));
+            if (rep && kprev == 0) printf("  pivot wave block 2: read %lld  self-update %lld  pivots %lld  publish %lld  barrier %lld  | iteration %lld ;  tile wave 3: wait %lld  update+gather %lld\n", st[17]-st[16], st[18]-st[17], st[19]-st[18], st[20]-st[19], st[21]-st[20], st[24]-st[16], st[13]-st[12], st[14]-st[13]);
             if (rep) printf("diag64 kprev=%3d: load %lld  mfma %lld  loop %lld  store %lld  total %lld ticks (%.1f us @2.35GHz)\n", kprev, st[1]-st[0], st[2]-st[1], st[3]-st[2], st[4]-st[3], st[4]-st[0], (st[4]-st[0])/2350.0);
         }
     }
