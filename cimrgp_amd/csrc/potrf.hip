@@ -684,8 +684,9 @@ static int panel_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info,
 // ---------------------------------------------------------------------------
 namespace {
 struct LookAhead {
-    hipStream_t side = nullptr;        // panel chain (high priority)
-    hipStream_t rows = nullptr;        // carried rows: lags behind the factorisation, lowest priority
+    hipStream_t side = nullptr;        // panel chain (high priority, all compute units)
+    hipStream_t bulk = nullptr;        // trailing updates: every compute unit but the reserved ones
+    hipStream_t rows = nullptr;        // carried rows: lags behind the factorisation; same mask as bulk
     std::vector<hipEvent_t> ev;
     int device = -1;
 };
@@ -700,7 +701,28 @@ LookAhead* lookahead_ctx(size_t nevents)
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         if (hipStreamCreateWithPriority(&la.side, hipStreamNonBlocking, hi) != hipSuccess) { la.side = nullptr; return nullptr; }
-        if (hipStreamCreateWithPriority(&la.rows, hipStreamNonBlocking, lo) != hipSuccess) la.rows = nullptr;
+        // Optional (CIMRGP_RESERVE_CUS = R, default 0 = off): reserve R compute units of every XCD
+        // for the latency-bound chain by running the MFMA-bound update kernels on queues whose CU
+        // mask excludes them.  Mask bit b is CU b / 8 of XCD b % 8 (measured: a mask that thins out
+        // ONE XCD slows a kernel by that XCD's loss, because workgroups are dealt round-robin to
+        // the XCDs), so the low 8 R bits take R CUs from each of the 8 XCDs and cost the update
+        // R / 32 of its rate.  Measured effect: what stretches a chain kernel beside a running
+        // update is not its execution but the WAIT FOR A SLOT -- two update workgroups fill a CU's
+        // registers and LDS -- (the single-workgroup diagonal kernel: 56..220 us between its events,
+        // 20 us inside; with R = 1: 29 us).  The chain's wide links (panel solve, head update)
+        // need the whole machine and wait just the same, so the end-to-end time does not move
+        // (N = 8192: 7.77 vs 7.79 ms; with carried rows 10.7 vs 9.6 ms): off by default.
+        const char* env = getenv("CIMRGP_RESERVE_CUS");
+        const int reserve = env ? atoi(env) : 0;
+        hipDeviceProp_t prop;
+        if (reserve > 0 && reserve < 8 && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount == 256) {
+            uint32_t mask[8];
+            for (int wd = 0; wd < 8; ++wd) mask[wd] = 0xffffffffu;
+            for (int bit = 0; bit < 8 * reserve; ++bit) mask[bit >> 5] &= ~(1u << (bit & 31));
+            if (hipExtStreamCreateWithCUMask(&la.bulk, 8, mask) != hipSuccess) la.bulk = nullptr;
+            if (hipExtStreamCreateWithCUMask(&la.rows, 8, mask) != hipSuccess) la.rows = nullptr;
+        }
+        if (la.rows == nullptr && hipStreamCreateWithPriority(&la.rows, hipStreamNonBlocking, lo) != hipSuccess) la.rows = nullptr;
         la.device = dev;
     }
     while (la.ev.size() < nevents) {
@@ -771,6 +793,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     }
 
     hipStream_t sp = la->side;
+    hipStream_t sb = la->bulk ? la->bulk : st;         // bulk trailing updates
     size_t ne = 0;
     // The side stream runs the whole latency-bound chain in stream order -- "head" update of the
     // next panel's columns, then that panel's factorisation -- so that no inter-queue signal
@@ -778,11 +801,10 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     // update (and, off the chain, the carried rows).  Cross-stream edges: "panel final"
     // (side -> main, before the bulk update that reads it) and "bulk update done" (main -> side,
     // before the next head touches columns the bulk update wrote).
-    // (Reserving CUs for the chain with a CU-masked bulk stream was measured and rejected: a
-    // masked queue ran the trailing update 20 % slower even with 8 of 256 CUs masked.)
     hipEvent_t ev_start = la->ev[ne++];
     CIMRGP_HIP_TRY(hipEventRecord(ev_start, st), "hipEventRecord");
     CIMRGP_HIP_TRY(hipStreamWaitEvent(sp, ev_start, 0), "hipStreamWaitEvent");
+    if (sb != st) CIMRGP_HIP_TRY(hipStreamWaitEvent(sb, ev_start, 0), "hipStreamWaitEvent");
     int rc = factor_panel<T>(k, n, ld, ws, info, 0, (n < CIMRGP_NB) ? n : CIMRGP_NB, sp);
     if (rc) return rc;
     hipEvent_t ev_panel = la->ev[ne++];
@@ -815,19 +837,19 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
             ev_panel = la->ev[ne++];
             CIMRGP_HIP_TRY(hipEventRecord(ev_panel, sp), "hipEventRecord");
         }
-        CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_go, 0), "hipStreamWaitEvent");
         if (k1 < n) {
             // bulk: lower SYRK beyond the next panel, concurrently with the chain
             ev_rest = nullptr;
             if (n > k2) {
+                CIMRGP_HIP_TRY(hipStreamWaitEvent(sb, ev_go, 0), "hipStreamWaitEvent");
                 const double mm = (double)(n - k2);
-                TrailRec* rec = rec_open(st, mm * (mm + 1.0) * (double)w);
+                TrailRec* rec = rec_open(sb, mm * (mm + 1.0) * (double)w);
                 rc = gemm_nt_sub<T>(k + k2 * ld + k2, ld, k + k2 * ld + k0, ld, k + k2 * ld + k0, ld,
-                                    n - k2, n - k2, (int)w, true, st);
-                if (rec) (void)hipEventRecord(rec->stop, st);
+                                    n - k2, n - k2, (int)w, true, sb);
+                if (rec) (void)hipEventRecord(rec->stop, sb);
                 if (rc) return rc;
                 ev_rest = la->ev[ne++];
-                CIMRGP_HIP_TRY(hipEventRecord(ev_rest, st), "hipEventRecord");
+                CIMRGP_HIP_TRY(hipEventRecord(ev_rest, sb), "hipEventRecord");
             }
         }
         if (rows) {
@@ -862,6 +884,9 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
         CIMRGP_HIP_TRY(hipEventRecord(ev_rows_done, la->rows), "hipEventRecord");
         CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_rows_done, 0), "hipStreamWaitEvent");
     }
+    // join: the last panel (side stream); every bulk update precedes it through the chain's waits
+    CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0), "hipStreamWaitEvent");
+    if (sb != st && ev_rest) CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_rest, 0), "hipStreamWaitEvent");
     return build_invT<T>(k, n, ld, ws, st);
 }
 

@@ -143,5 +143,32 @@ int main()
             hipStreamDestroy(sm);
         }
     }
+    {   // diag64 next to a running trailing update: is it the launch or the execution that stretches?
+        const int nn = 8192; const int64_t l2 = 8192;
+        double* dA; hipMalloc(&dA, (size_t)nn * l2 * 8); hipMemset(dA, 0, (size_t)nn * l2 * 8);
+        for (int reserve = 0; reserve <= 2; ++reserve) {
+            uint32_t mask[8]; for (int i = 0; i < 8; ++i) mask[i] = 0xffffffffu;
+            for (int bit = 0; bit < 8 * reserve; ++bit) mask[bit >> 5] &= ~(1u << (bit & 31));
+            hipStream_t sg, sc; int lo, hi; hipDeviceGetStreamPriorityRange(&lo, &hi);
+            hipExtStreamCreateWithCUMask(&sg, 8, mask);
+            hipStreamCreateWithPriority(&sc, hipStreamNonBlocking, hi);
+            for (int rep = 0; rep < 3; ++rep) {
+                hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+                for (int gk = 0; gk < 3; ++gk)
+                    gemm_nt_sub<double>(dA + 256 * l2 + 256, l2, dA + 256 * l2, l2, dA + 256 * l2, l2, 7936, 7936, 256, true, sg);
+                // let the update get going, then the chain kernel
+                for (volatile int spin = 0; spin < 200000; ++spin) {}
+                hipEventRecord(e0, sc);
+                hipLaunchKernelGGL((k_diag64<double>), dim3(1), dim3(DG_NT), 0, sc, dK + (size_t)256 * ld + 256, (int64_t)ld, 64, dK + (size_t)256 * ld + 256, 0, dws, dinfo, 0);
+                hipEventRecord(e1, sc);
+                hipDeviceSynchronize();
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamp), sizeof(st));
+                if (rep) printf("reserve %d CU/XCD: diag64 beside the update: events %.1f us, inside the kernel %.1f us (load %lld mfma %lld loop %lld store %lld)\n",
+                                reserve, ms * 1e3, (st[4] - st[0]) / 2350.0, st[1]-st[0], st[2]-st[1], st[3]-st[2], st[4]-st[3]);
+            }
+            hipStreamDestroy(sg); hipStreamDestroy(sc);
+        }
+    }
     return 0;
 }
