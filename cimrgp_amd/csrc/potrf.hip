@@ -12,6 +12,7 @@
 // are what cimrgp_potrs / cimrgp_trsm_rows use afterwards.
 #include "common.hpp"
 #include <cstdlib>
+#include <mutex>
 
 #include <vector>
 
@@ -689,6 +690,7 @@ struct LookAhead {
     hipStream_t rows = nullptr;        // carried rows: lags behind the factorisation; same mask as bulk
     std::vector<hipEvent_t> ev;
     int device = -1;
+    std::mutex enqueue;                // one factorisation at a time enqueues on this device's side queues
 };
 LookAhead g_la[16];
 
@@ -792,6 +794,9 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
         return rc0 ? rc0 : build_invT<T>(k, n, ld, ws, st);
     }
 
+    // Host threads driving the same device share the side queues and the event pool: serialise the
+    // ENQUEUE (microseconds); the queued work of two factorisations may still overlap on the GPU.
+    std::lock_guard<std::mutex> guard(la->enqueue);
     hipStream_t sp = la->side;
     hipStream_t sb = la->bulk ? la->bulk : st;         // bulk trailing updates
     size_t ne = 0;
