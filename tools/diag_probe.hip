@@ -103,6 +103,22 @@ int main()
             }
         }
     }
+    {   // deeper K per pass: lower update of M = 7424 with K = 256, 512, 768 (C traffic per flop halves / thirds)
+        const int nn = 8192; const int64_t l2 = 8192;
+        double* dA; hipMalloc(&dA, (size_t)nn * l2 * 8); hipMemset(dA, 0, (size_t)nn * l2 * 8);
+        for (int K : {256, 512, 768}) {
+            float best = 1e9f;
+            for (int rep = 0; rep < 3; ++rep) {
+                hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+                hipEventRecord(e0);
+                gemm_nt_sub<double>(dA + 768 * l2 + 768, l2, dA + 768 * l2, l2, dA + 768 * l2, l2, 7424, 7424, K, true, 0);
+                hipEventRecord(e1); hipDeviceSynchronize();
+                float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+            }
+            printf("lower gemm M=7424 K=%d: %.1f us  (%.1f TF/s)\n", K, best * 1e3, 7424.0 * 7425.0 * K / (best * 1e-3) / 1e12);
+        }
+        hipFree(dA);
+    }
     {   // rectangular update of carried rows: M = 2048 rows x N columns, K = 256
         const int nn = 8192; const int64_t l2 = 8208;
         double *dA, *dB2; hipMalloc(&dA, (size_t)nn * l2 * 8); hipMemset(dA, 0, (size_t)nn * l2 * 8);
