@@ -78,8 +78,11 @@ def main():
     if args.gpus > 1 or world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        torch.cuda.set_device(local_rank)
-        td.init_process_group("nccl", rank=rank, world_size=world)
+        # CIMRGP_BENCH_REHEARSAL=gloo: rehearse the N > 1 path on a box with ONE GPU (all ranks on
+        # cuda:0, gloo carrying the device tensors); the driver's multi-GPU runs use nccl = RCCL
+        rehearsal = os.environ.get("CIMRGP_BENCH_REHEARSAL", "")
+        torch.cuda.set_device(0 if rehearsal else local_rank)
+        td.init_process_group(rehearsal or "nccl", rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     device = dev.require_gpu()
