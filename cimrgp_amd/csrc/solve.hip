@@ -141,6 +141,25 @@ void k_bwd_panel(const T* __restrict__ L, int64_t ld, int n, const T* __restrict
     __shared__ T zs[Q][PW];
     __shared__ T red[16][Q][SB];
     const int tid = threadIdx.x;
+    // this thread's 16 elements of L for the update below: requested first, so that their round
+    // trip overlaps the redundant inverse apply (they do not depend on it)
+    const int t = tid & 63, part = tid >> 6;                      // 16 row parts of 16
+    const int col = blockIdx.x * SB + t;
+    const int ubeg = part * 16;
+    T lv[16];
+    if (col < k0) {
+        const T* lp = L + (int64_t)k0 * ld + col;
+        if (w == PW) {                                 // full panel: unconditional, independent loads
+#pragma unroll
+            for (int e = 0; e < 16; ++e) lv[e] = lp[(int64_t)(ubeg + e) * ld];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) lv[e] = (ubeg + e < w) ? lp[(int64_t)(ubeg + e) * ld] : (T)0;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) lv[e] = (T)0;
+    }
     for (int e = tid; e < Q * PW; e += ST) {
         const int c = e / PW, u = e - c * PW;
         ws_[c][u] = (u < w) ? work[(int64_t)c * n + k0 + u] : (T)0;
@@ -182,22 +201,10 @@ void k_bwd_panel(const T* __restrict__ L, int64_t ld, int n, const T* __restrict
         }
     }
     __syncthreads();
-    const int t = tid & 63, part = tid >> 6;                      // 16 row parts of 16
-    const int col = blockIdx.x * SB + t;
     T acc[Q];
 #pragma unroll
     for (int c = 0; c < Q; ++c) acc[c] = (T)0;
     if (col < k0) {
-        const T* lp = L + (int64_t)k0 * ld + col;
-        const int ubeg = part * 16;
-        T lv[16];
-        if (w == PW) {                                 // full panel: unconditional, independent loads
-#pragma unroll
-            for (int e = 0; e < 16; ++e) lv[e] = lp[(int64_t)(ubeg + e) * ld];
-        } else {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) lv[e] = (ubeg + e < w) ? lp[(int64_t)(ubeg + e) * ld] : (T)0;
-        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
 #pragma unroll
