@@ -228,3 +228,28 @@ def test_sinkhorn_omega_agrees_with_minpack(monkeypatch):
     assert np.max(np.abs(stats.omega.sum(0) - 1.0)) < 1e-12 and np.max(np.abs(stats.omega.sum(1) - 1.0)) < 1e-12
     assert np.max(np.abs(ref.sum(0) - 1.0)) < 1e-6
     assert np.max(np.abs(stats.omega - ref)) < 1e-6 * np.max(ref)
+
+
+def test_random_region_index_sets(numpy_device):
+    """IndexSetUniform(n_regions=[...]): random contiguous regions (IndexSetGenerator.py:67-92),
+    test regions given by ``number_of_regions``; against the pinned oracle on the same bounds."""
+    from oracle.reduced import ReducedRankModel
+    rng = np.random.default_rng(2)
+    n, ns = 300, 120
+    x = np.sort(rng.uniform(1, 3, size=(n, 1)), axis=0)
+    y = np.hstack([np.sin(3 * x), np.cos(2 * x)]) + 0.05 * rng.normal(size=(n, 2))
+    xs = np.sort(rng.uniform(1, 3, size=(ns, 1)), axis=0)
+    np.random.seed(5)
+    idx = IndexSetUniform(n, 1, None, n_regions=[1, 3])
+    idx_t = IndexSetUniform(ns, 1, None, n_regions=[1, 3])
+    assert [len(b) for b in idx.bounds] == [1, 3] and idx.bounds[1][0][0] == 0 and idx.bounds[1][-1][1] == n
+    model = MultiResolutionGaussianProcess(train_xy=[x, y], n_basis=10, index_set_obj=idx,
+                                           basis_function_obj=LaplacianEigenpairs(),
+                                           spectral_density_obj=MaternKernel(nu=1, l=1, sf=1), forced_independence=True)
+    model.fit(3, None)
+    got = model.get_predicted_mean(xs, idx_t, number_of_regions=[1, 3])
+    omodel = ReducedRankModel(x, y, idx.bounds, 10, forced_independence=True)
+    omodel.fit(3)
+    assert _rel(got, omodel.predict_mean(xs, idx_t.bounds)) < 1e-9
+    with pytest.raises(ValueError):
+        model.get_predicted_mean(xs, idx_t, number_of_regions=[1, 2])
