@@ -245,9 +245,11 @@ int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t 
     CIMRGP_REQUIRE(aligned16(a) && aligned16(b), fn, "operand base not 16-byte aligned");
     CIMRGP_REQUIRE(lda % Mx<T>::EPC == 0 && ldb % Mx<T>::EPC == 0, fn, "leading dimension not a multiple of 16 bytes");
     CIMRGP_REQUIRE(!lower || m == n, fn, "lower update needs a square C");
-    // fewer than ~2 workgroups per CU with 128-tiles: use 64-tiles (4x the workgroups, 1/4 the work each)
+    // fewer than ~3 workgroups per CU with 128-tiles: use 64-tiles (4x the workgroups, 1/4 the work
+    // each; measured sweep of the switch point inside the factorisation at N = 8192:
+    // 256/512/768/1024/1536 tiles -> 91.3/93.5/94.2/91.9/90.6 posteriors/s)
     const int64_t t128 = ((m + 127) / 128) * ((n + 127) / 128) / (lower ? 2 : 1);
-    if (t128 < 512) return gemm_launch<T, 2>(c, ldc, a, lda, b, ldb, m, n, k, lower, st);
+    if (t128 < 768) return gemm_launch<T, 2>(c, ldc, a, lda, b, ldb, m, n, k, lower, st);
     return gemm_launch<T, 4>(c, ldc, a, lda, b, ldb, m, n, k, lower, st);
 }
 
