@@ -308,3 +308,18 @@ def test_reference_example_recipe(ca):
         out = mod.run(train, test, n_res=1, divider=2, n_basis=15, n_iter=10, forced_independence=forced)
         assert np.isfinite(out["mll"]) and np.isfinite(out["mse"])
         assert out["r2"] > 0.5, out
+
+
+def test_second_reference_example_recipe(ca):
+    """scripts/tests/GPRBF_vs_ciMRGP_vs_fiMRGP.py: optimised exact RBF GP beside ciMRGP / fiMRGP."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples",
+                        "gprbf_vs_cimrgp_vs_fimrgp.py")
+    spec = importlib.util.spec_from_file_location("cimrgp_example2", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    train, test = mod.base.generate_data(n_train=160, n_test=5000)
+    out = mod.run_gp_rbf(train, test)
+    assert np.isfinite(out["mll"]) and out["r2"] > 0.8, out
+    ci = mod.base.run(train, test, n_res=2, divider=2, n_basis=15, n_iter=10, forced_independence=False)
+    assert np.isfinite(ci["mll"]) and ci["r2"] > 0.5, ci
