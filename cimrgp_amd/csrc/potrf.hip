@@ -72,6 +72,11 @@ static TrailRec* rec_open(hipStream_t st, double flops)
 namespace {
 
 constexpr int SB = 64;   // diagonal sub-block
+// Far part of the trailing matrix updated once per two panels while larger than this.  Measured:
+// N = 65536 (config 3) fit 3.54 -> 2.41 s; at N = 8192 pairing (thresholds 2048..6144) raises the
+// update kernel's rate (49 -> 56 % of peak) but not the end-to-end time (longer-lived update
+// workgroups, longer slot waits of the chain), so it starts above that size.
+constexpr int64_t FAR_PAIR_ABOVE = 8192;
 constexpr int64_t HEAD_FIRST_ABOVE = 4608;   // the bulk update waits for the head update while the trailing matrix is larger
 constexpr int64_t ROWS_START_BELOW = 4608;   // carried rows start once the trailing matrix is smaller than this
 
@@ -815,6 +820,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     hipEvent_t ev_panel = la->ev[ne++];
     CIMRGP_HIP_TRY(hipEventRecord(ev_panel, sp), "hipEventRecord");
     hipEvent_t ev_rest = nullptr;                      // bulk update of the previous panel
+    int64_t pair_k0 = -1;                              // first panel of a pair whose far update is still owed
     int64_t rows_next = 0;                             // first panel the carried rows have not seen yet
     for (int64_t k0 = 0; k0 < n; k0 += CIMRGP_NB) {
         const int64_t w  = (n - k0 < CIMRGP_NB) ? (n - k0) : CIMRGP_NB;
@@ -843,16 +849,30 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
             CIMRGP_HIP_TRY(hipEventRecord(ev_panel, sp), "hipEventRecord");
         }
         if (k1 < n) {
-            // bulk: lower SYRK beyond the next panel, concurrently with the chain
+            // bulk: lower SYRK beyond the next panel, concurrently with the chain.  While that far
+            // region is big, it is updated once per TWO panels with K = 512 (adjacent panels are
+            // adjacent columns, the same kernel applies): half the passes over C.  The first
+            // panel of a pair then only updates the columns of the panel after next ("near").
             ev_rest = nullptr;
             if (n > k2) {
                 CIMRGP_HIP_TRY(hipStreamWaitEvent(sb, ev_go, 0), "hipStreamWaitEvent");
-                const double mm = (double)(n - k2);
-                TrailRec* rec = rec_open(sb, mm * (mm + 1.0) * (double)w);
-                rc = gemm_nt_sub<T>(k + k2 * ld + k2, ld, k + k2 * ld + k0, ld, k + k2 * ld + k0, ld,
-                                    n - k2, n - k2, (int)w, true, sb);
-                if (rec) (void)hipEventRecord(rec->stop, sb);
-                if (rc) return rc;
+                const int64_t wnn = (n - k2 < CIMRGP_NB) ? (n - k2) : CIMRGP_NB;   // panel after next
+                const int64_t k3 = k2 + wnn;
+                if (pair_k0 < 0 && n - k3 > FAR_PAIR_ABOVE) {
+                    rc = gemm_nt_sub<T>(k + k2 * ld + k2, ld, k + k2 * ld + k0, ld, k + k2 * ld + k0, ld,
+                                        n - k2, wnn, (int)w, false, sb);
+                    if (rc) return rc;
+                    pair_k0 = k0;
+                } else {
+                    const int64_t kk0 = (pair_k0 >= 0) ? pair_k0 : k0;
+                    const double mm = (double)(n - k2);
+                    TrailRec* rec = rec_open(sb, mm * (mm + 1.0) * (double)(k1 - kk0));
+                    rc = gemm_nt_sub<T>(k + k2 * ld + k2, ld, k + k2 * ld + kk0, ld, k + k2 * ld + kk0, ld,
+                                        n - k2, n - k2, (int)(k1 - kk0), true, sb);
+                    if (rec) (void)hipEventRecord(rec->stop, sb);
+                    if (rc) return rc;
+                    pair_k0 = -1;
+                }
                 ev_rest = la->ev[ne++];
                 CIMRGP_HIP_TRY(hipEventRecord(ev_rest, sb), "hipEventRecord");
             }

@@ -146,6 +146,38 @@ def test_full_size_properties_n8192(ca):
     assert float((m - want).abs().max()) < 1e-7
 
 
+def test_two_panel_far_updates_n10240(ca):
+    """N = 10240: large enough for the factorisation to update the far part of the trailing matrix
+    once per two panels (K = 512); checksum K v = L (L^T v), LAPACK on the leading minor, and the
+    carried-rows variant against the plain one."""
+    dev = ca.device
+    rng = np.random.default_rng(99)
+    n = 10240
+    x = np.sort(rng.uniform(-2.0, 2.0, size=(n, 1)), axis=0)
+    ell, sf2, noise = 0.1, 1.0, 0.01
+    xd = dev.to_device(x, torch.float64, "cuda")
+    kbuf = dev.rbf_gram(xd, ell, sf2, noise, lower_only=False)
+    kfull = kbuf[:n, :n].clone()
+    ws, info = dev.potrf(kbuf, n)
+    assert int(info.item()) == 0
+    lmat = torch.tril(kbuf[:n, :n])
+    v = torch.from_numpy(rng.normal(size=(n, 3))).cuda()
+    rhs = kfull @ v
+    assert float((lmat @ (lmat.t() @ v) - rhs).abs().max() / rhs.abs().max()) < 1e-11
+    lref, _ = oracle.potrf_lower(oracle.rbf_gram(x[:1536], None, ell, sf2, noise))
+    assert _relerr(lmat[:1536, :1536].cpu().numpy(), lref) < 1e-9
+    # the last rows see every pair: compare the bottom-right corner with a second, rows-carrying run
+    k2 = dev.rbf_gram(xd, ell, sf2, noise, lower_only=True)
+    w = dev.alloc_matrix(64, n, torch.float64, "cuda")
+    w[:64, :n] = torch.from_numpy(rng.normal(size=(64, n))).cuda()
+    w0 = w[:64, :n].clone()
+    _, info2 = dev.potrf_rows(k2, n, w, 64)
+    assert int(info2.item()) == 0
+    assert float((torch.tril(k2[:n, :n]) - lmat).abs().max()) < 1e-12
+    back = w[:64, :n] @ lmat.t()                    # (B L^-T) L^T = B
+    assert float((back - w0).abs().max() / w0.abs().max()) < 1e-9
+
+
 def _two_rank_worker(rank, world, port, out_dir):
     import os
     import sys
