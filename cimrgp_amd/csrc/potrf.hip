@@ -78,6 +78,7 @@ constexpr int SB = 64;   // diagonal sub-block
 // workgroups, longer slot waits of the chain), so it starts above that size.
 constexpr int64_t FAR_PAIR_ABOVE = 8192;
 constexpr int64_t HEAD_FIRST_ABOVE = 4608;   // the bulk update waits for the head update while the trailing matrix is larger
+constexpr int64_t ROWS_PAIR_ABOVE_SOLVE = 1024;   // stand-alone row-wise solve: pair the updates while more columns remain
 constexpr int64_t ROWS_START_BELOW = 4608;   // carried rows start once the trailing matrix is smaller than this
 
 
@@ -622,20 +623,46 @@ void k_invT_step(T* __restrict__ invT, const T* __restrict__ L, int64_t ld, int 
 // One pass over the panels.  With FACTOR the matrix itself is factored; with
 // rows (b != nullptr) the extra rows are carried through the same panel
 // operations, which turns them into  B L^-T.
+// One panel of a row-wise solve  B <- B L^-T : the 256-wide solve of the panel's columns, then
+// the update of the columns right of it.  While more than `pair_above` columns lie beyond the
+// next panel, the update is done once per TWO panels with K = 512 (half the passes over B): the
+// first panel of a pair only updates the next panel's columns, the second one everything right
+// of itself with both panels (adjacent panels are adjacent columns of B and of L).
+template <typename T>
+static int rows_panel_step(T* b, int64_t ldb, int64_t m, const T* lmat, int64_t ld, int64_t n, const T* ws,
+                           int64_t r0, int64_t& pair_r0, int64_t pair_above, hipStream_t st, const char* fn)
+{
+    const int64_t rw = (n - r0 < CIMRGP_NB) ? (n - r0) : CIMRGP_NB;
+    const int64_t r1 = r0 + rw;
+    hipLaunchKernelGGL((k_trsm256<T>), dim3((unsigned)((m + TR - 1) / TR)), dim3(256), 0, st,
+                       b + r0, ldb, (int)m, (int)rw, (const T*)(lmat + r0 * ld + r0), ld,
+                       (const T*)(ws + (r0 / SB) * (SB * SB)));
+    CIMRGP_LAUNCH_CHECK(fn);
+    if (n <= r1) { pair_r0 = -1; return 0; }
+    const int64_t rn = (n - r1 < CIMRGP_NB) ? (n - r1) : CIMRGP_NB;
+    if (pair_r0 < 0 && n - (r1 + rn) > pair_above) {
+        pair_r0 = r0;
+        return gemm_nt_sub<T>(b + r1, ldb, b + r0, ldb, lmat + r1 * ld + r0, ld, m, rn, (int)rw, false, st);
+    }
+    const int64_t kk0 = (pair_r0 >= 0) ? pair_r0 : r0;
+    pair_r0 = -1;
+    return gemm_nt_sub<T>(b + r1, ldb, b + kk0, ldb, lmat + r1 * ld + kk0, ld, m, n - r1, (int)(r1 - kk0), false, st);
+}
+
 template <typename T, bool FACTOR>
 static int panel_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info,
                        T* b, int64_t m, int64_t ldb, hipStream_t st)
 {
     const char* fn = FACTOR ? "cimrgp_potrf" : "cimrgp_trsm_rows";
     const bool rows = (b != nullptr && m > 0);
+    int64_t pair_r0 = -1;
     for (int64_t k0 = 0; k0 < n; k0 += CIMRGP_NB) {
         const int64_t w = (n - k0 < CIMRGP_NB) ? (n - k0) : CIMRGP_NB;
         const int64_t k1 = k0 + w;
         if (!FACTOR && rows) {
-            hipLaunchKernelGGL((k_trsm256<T>), dim3((unsigned)((m + TR - 1) / TR)), dim3(256), 0, st,
-                               b + k0, ldb, (int)m, (int)w, (const T*)(kmat + k0 * ld + k0), ld,
-                               (const T*)(ws + (k0 / SB) * (SB * SB)));
-            CIMRGP_LAUNCH_CHECK(fn);
+            int rc = rows_panel_step<T>(b, ldb, m, kmat, ld, n, ws, k0, pair_r0, ROWS_PAIR_ABOVE_SOLVE, st, fn);
+            if (rc) return rc;
+            continue;
         }
         for (int64_t c0 = k0; FACTOR && c0 < k1; c0 += SB) {
             const int sw = (int)((k1 - c0 < SB) ? (k1 - c0) : SB);
@@ -822,6 +849,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     hipEvent_t ev_rest = nullptr;                      // bulk update of the previous panel
     int64_t pair_k0 = -1;                              // first panel of a pair whose far update is still owed
     int64_t rows_next = 0;                             // first panel the carried rows have not seen yet
+    int64_t rows_pair_r0 = -1;                         // carried rows: first panel of a pair whose far update is owed
     for (int64_t k0 = 0; k0 < n; k0 += CIMRGP_NB) {
         const int64_t w  = (n - k0 < CIMRGP_NB) ? (n - k0) : CIMRGP_NB;
         const int64_t k1 = k0 + w;
@@ -888,17 +916,10 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
             const bool defer = (sq != st) && (n - k1 > ROWS_START_BELOW) && (k1 < n);
             if (!defer) {
                 if (sq != st) CIMRGP_HIP_TRY(hipStreamWaitEvent(sq, ev_final, 0), "hipStreamWaitEvent");
+                // (pairing the rows' updates below that size was measured neutral-to-worse at N = 8192)
                 for (int64_t r0 = rows_next; r0 <= k0; r0 += CIMRGP_NB) {
-                    const int64_t rw = (n - r0 < CIMRGP_NB) ? (n - r0) : CIMRGP_NB;
-                    const int64_t r1 = r0 + rw;
-                    hipLaunchKernelGGL((k_trsm256<T>), dim3((unsigned)((m + TR - 1) / TR)), dim3(256), 0, sq,
-                                       b + r0, ldb, (int)m, (int)rw, (const T*)(k + r0 * ld + r0), ld,
-                                       (const T*)(ws + (r0 / SB) * (SB * SB)));
-                    CIMRGP_LAUNCH_CHECK("cimrgp_potrf_rows");
-                    if (n > r1) {
-                        rc = gemm_nt_sub<T>(b + r1, ldb, b + r0, ldb, k + r1 * ld + r0, ld, m, n - r1, (int)rw, false, sq);
-                        if (rc) return rc;
-                    }
+                    rc = rows_panel_step<T>(b, ldb, m, k, ld, n, ws, r0, rows_pair_r0, FAR_PAIR_ABOVE, sq, "cimrgp_potrf_rows");
+                    if (rc) return rc;
                 }
                 rows_next = k1;
             }
