@@ -140,7 +140,7 @@ def test_potrs(dev, dt, tol, n, q):
     assert _relerr(rhs.double().cpu().numpy(), fit["alpha"]) < tol
 
 
-@pytest.mark.parametrize("n,m", [(64, 5), (257, 130), (700, 64), (512, 1000)])
+@pytest.mark.parametrize("n,m", [(64, 5), (257, 130), (700, 64), (512, 1000), (2500, 70), (3072, 33)])
 def test_trsm_rows_f64(dev, n, m):
     x, _ = _data(n, 2, seed=n)
     xs, _ = _data(m, 2, seed=n + 1)

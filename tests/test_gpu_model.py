@@ -146,6 +146,23 @@ def test_full_size_properties_n8192(ca):
     assert float((m - want).abs().max()) < 1e-7
 
 
+def test_two_panel_far_updates_ragged_n9001(ca):
+    """Just past the pairing threshold with a ragged last panel (9001 = 35 panels + 41 columns)."""
+    dev = ca.device
+    rng = np.random.default_rng(7)
+    n = 9001
+    x = np.sort(rng.uniform(-2.0, 2.0, size=(n, 1)), axis=0)
+    xd = dev.to_device(x, torch.float64, "cuda")
+    kbuf = dev.rbf_gram(xd, 0.1, 1.0, 0.01, lower_only=False)
+    kfull = kbuf[:n, :n].clone()
+    _, info = dev.potrf(kbuf, n)
+    assert int(info.item()) == 0
+    lmat = torch.tril(kbuf[:n, :n])
+    v = torch.from_numpy(rng.normal(size=(n, 2))).cuda()
+    rhs = kfull @ v
+    assert float((lmat @ (lmat.t() @ v) - rhs).abs().max() / rhs.abs().max()) < 1e-11
+
+
 def test_two_panel_far_updates_n10240(ca):
     """N = 10240: large enough for the factorisation to update the far part of the trailing matrix
     once per two panels (K = 512); checksum K v = L (L^T v), LAPACK on the leading minor, and the
