@@ -820,7 +820,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     const bool rows = (b != nullptr && m > 0);
     CIMRGP_HIP_TRY(hipMemsetAsync(info, 0, sizeof(int32_t), st), "hipMemsetAsync(info)");
     const int64_t npanels = (n + CIMRGP_NB - 1) / CIMRGP_NB;
-    LookAhead* la = (npanels > 2) ? lookahead_ctx((size_t)(5 * npanels + 8)) : nullptr;
+    LookAhead* la = (npanels > 2) ? lookahead_ctx((size_t)(6 * npanels + 8)) : nullptr;
     if (la == nullptr) {
         int rc0 = panel_sweep<T, true>(k, n, ld, ws, info, b, m, ldb, st);
         return rc0 ? rc0 : build_invT<T>(k, n, ld, ws, st);
@@ -848,6 +848,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     CIMRGP_HIP_TRY(hipEventRecord(ev_panel, sp), "hipEventRecord");
     hipEvent_t ev_rest = nullptr;                      // bulk update of the previous panel
     int64_t pair_k0 = -1;                              // first panel of a pair whose far update is still owed
+    hipEvent_t ev_bulk_last = nullptr;                 // last thing queued on the bulk stream
     int64_t rows_next = 0;                             // first panel the carried rows have not seen yet
     int64_t rows_pair_r0 = -1;                         // carried rows: first panel of a pair whose far update is owed
     for (int64_t k0 = 0; k0 < n; k0 += CIMRGP_NB) {
@@ -882,6 +883,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
             // adjacent columns, the same kernel applies): half the passes over C.  The first
             // panel of a pair then only updates the columns of the panel after next ("near").
             ev_rest = nullptr;
+            bool split_far = false;                // the split far update records its own events
             if (n > k2) {
                 CIMRGP_HIP_TRY(hipStreamWaitEvent(sb, ev_go, 0), "hipStreamWaitEvent");
                 const int64_t wnn = (n - k2 < CIMRGP_NB) ? (n - k2) : CIMRGP_NB;   // panel after next
@@ -891,6 +893,26 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
                                         n - k2, wnn, (int)w, false, sb);
                     if (rc) return rc;
                     pair_k0 = k0;
+                } else if (pair_k0 >= 0 && n > k3) {
+                    // second panel of a pair: first the columns of the panel after next (all the
+                    // chain's next head update needs -- it may start as soon as they are done),
+                    // then the big remainder, which overlaps the chain's next TWO panels
+                    const int kk = (int)(k1 - pair_k0);
+                    rc = gemm_nt_sub<T>(k + k2 * ld + k2, ld, k + k2 * ld + pair_k0, ld, k + k2 * ld + pair_k0, ld,
+                                        n - k2, wnn, kk, false, sb);
+                    if (rc) return rc;
+                    ev_rest = la->ev[ne++];
+                    CIMRGP_HIP_TRY(hipEventRecord(ev_rest, sb), "hipEventRecord");
+                    const double mm = (double)(n - k3);
+                    TrailRec* rec = rec_open(sb, mm * (mm + 1.0) * (double)kk);
+                    rc = gemm_nt_sub<T>(k + k3 * ld + k3, ld, k + k3 * ld + pair_k0, ld, k + k3 * ld + pair_k0, ld,
+                                        n - k3, n - k3, kk, true, sb);
+                    if (rec) (void)hipEventRecord(rec->stop, sb);
+                    if (rc) return rc;
+                    pair_k0 = -1;
+                    ev_bulk_last = la->ev[ne++];
+                    CIMRGP_HIP_TRY(hipEventRecord(ev_bulk_last, sb), "hipEventRecord");
+                    split_far = true;
                 } else {
                     const int64_t kk0 = (pair_k0 >= 0) ? pair_k0 : k0;
                     const double mm = (double)(n - k2);
@@ -901,8 +923,11 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
                     if (rc) return rc;
                     pair_k0 = -1;
                 }
-                ev_rest = la->ev[ne++];
-                CIMRGP_HIP_TRY(hipEventRecord(ev_rest, sb), "hipEventRecord");
+                if (!split_far) {
+                    ev_rest = la->ev[ne++];
+                    CIMRGP_HIP_TRY(hipEventRecord(ev_rest, sb), "hipEventRecord");
+                    ev_bulk_last = ev_rest;
+                }
             }
         }
         if (rows) {
@@ -932,7 +957,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     }
     // join: the last panel (side stream); every bulk update precedes it through the chain's waits
     CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0), "hipStreamWaitEvent");
-    if (sb != st && ev_rest) CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_rest, 0), "hipStreamWaitEvent");
+    if (sb != st && ev_bulk_last) CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_bulk_last, 0), "hipStreamWaitEvent");
     return build_invT<T>(k, n, ld, ws, st);
 }
 

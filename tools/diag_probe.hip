@@ -119,6 +119,26 @@ int main()
         }
         hipFree(dA);
     }
+    {   // the same at M = 15360 and 32256 (2 GB / 8.5 GB matrices)
+        for (int nn : {16384, 33280}) {
+            const int64_t l2 = nn + 16;
+            double* dA; if (hipMalloc(&dA, (size_t)nn * l2 * 8) != hipSuccess) continue;
+            hipMemset(dA, 0, (size_t)nn * l2 * 8);
+            const int M = nn - 1024;
+            for (int K : {256, 512, 768, 1024}) {
+                float best = 1e9f;
+                for (int rep = 0; rep < 2; ++rep) {
+                    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+                    hipEventRecord(e0);
+                    gemm_nt_sub<double>(dA + 1024 * l2 + 1024, l2, dA + 1024 * l2, l2, dA + 1024 * l2, l2, M, M, K, true, 0);
+                    hipEventRecord(e1); hipDeviceSynchronize();
+                    float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+                }
+                printf("lower gemm M=%d K=%d: %.1f us  (%.1f TF/s)\n", M, K, best * 1e3, (double)M * (M + 1.0) * K / (best * 1e-3) / 1e12);
+            }
+            hipFree(dA);
+        }
+    }
     {   // rectangular update of carried rows: M = 2048 rows x N columns, K = 256
         const int nn = 8192; const int64_t l2 = 8208;
         double *dA, *dB2; hipMalloc(&dA, (size_t)nn * l2 * 8); hipMemset(dA, 0, (size_t)nn * l2 * 8);
