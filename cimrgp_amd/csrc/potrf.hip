@@ -72,10 +72,11 @@ static TrailRec* rec_open(hipStream_t st, double flops)
 namespace {
 
 constexpr int SB = 64;   // diagonal sub-block
-// Far part of the trailing matrix updated once per two panels while larger than this.  Measured:
-// N = 65536 (config 3) fit 3.54 -> 2.41 s; at N = 8192 pairing (thresholds 2048..6144) raises the
-// update kernel's rate (49 -> 56 % of peak) but not the end-to-end time (longer-lived update
-// workgroups, longer slot waits of the chain), so it starts above that size.
+// Far part of the trailing matrix updated once per group of panels while larger than this.
+// Measured: whole potrf at N = 65536 1650 -> 1505 ms (56.9 -> 62.3 TF/s); at N = 8192 pairing
+// (thresholds 2048..6144) raises the update kernel's rate (49 -> 56 % of peak) but not the
+// end-to-end time (longer-lived update workgroups, longer slot waits of the chain), so it
+// starts above that size.
 constexpr int64_t FAR_PAIR_ABOVE = 8192;
 constexpr int64_t HEAD_FIRST_ABOVE = 4608;   // the bulk update waits for the head update while the trailing matrix is larger
 constexpr int64_t ROWS_PAIR_ABOVE_SOLVE = 1024;   // stand-alone row-wise solve: pair the updates while more columns remain
@@ -623,14 +624,35 @@ void k_invT_step(T* __restrict__ invT, const T* __restrict__ L, int64_t ld, int 
 // One pass over the panels.  With FACTOR the matrix itself is factored; with
 // rows (b != nullptr) the extra rows are carried through the same panel
 // operations, which turns them into  B L^-T.
+// How many panels share one pass over the far part of the matrix being updated (K = 256 x that
+// many).  Stand-alone rate of the update at K = 256 / 512 / 768 / 1024: 51.5 / 59.0 / 62.1 / 63.5
+// TF/s at M = 15360, 55.5 / 62.1 / 64.3 / 65.3 TF/s at M = 32256.  Inside the factorisation
+// (whole potrf, groups capped at 1 / 2 / 3 / 4): N = 32768: 217.8 / 203.9 / 201.3 / 200.9 ms,
+// N = 65536: 1650 / 1512 / 1505 / 1505 ms -- pairs bring most of it.  The group is also kept
+// small enough for the operand panel (far x K x 8 bytes) to fit the 256 MB Infinity Cache.
+static inline int group_size(int64_t far, int64_t pair_above)
+{
+    if (far <= pair_above) return 1;
+    const int by_benefit = (far > 32768) ? 4 : (far > 16384 ? 3 : 2);
+    const int64_t by_cache = ((int64_t)1 << 17) / far;       // 2^28 bytes / (8 bytes x far rows x 256 columns)
+    const int g = (by_cache < by_benefit) ? (int)by_cache : by_benefit;
+    return g < 1 ? 1 : g;
+}
+
+struct PanelGroup {
+    int64_t g0 = -1;      // first column of the group's first panel (-1: no group open)
+    int left = 0;         // panels of the group still to come, this one included
+};
+
 // One panel of a row-wise solve  B <- B L^-T : the 256-wide solve of the panel's columns, then
 // the update of the columns right of it.  While more than `pair_above` columns lie beyond the
-// next panel, the update is done once per TWO panels with K = 512 (half the passes over B): the
-// first panel of a pair only updates the next panel's columns, the second one everything right
-// of itself with both panels (adjacent panels are adjacent columns of B and of L).
+// next panel, the far columns are updated once per GROUP of panels with K = 256 x group size
+// (fewer passes over B): every panel of a group but the last only updates the next panel's
+// columns (with all the group's panels so far), the last one everything right of itself
+// (adjacent panels are adjacent columns of B and of L).
 template <typename T>
 static int rows_panel_step(T* b, int64_t ldb, int64_t m, const T* lmat, int64_t ld, int64_t n, const T* ws,
-                           int64_t r0, int64_t& pair_r0, int64_t pair_above, hipStream_t st, const char* fn)
+                           int64_t r0, PanelGroup& grp, int64_t pair_above, hipStream_t st, const char* fn)
 {
     const int64_t rw = (n - r0 < CIMRGP_NB) ? (n - r0) : CIMRGP_NB;
     const int64_t r1 = r0 + rw;
@@ -638,14 +660,18 @@ static int rows_panel_step(T* b, int64_t ldb, int64_t m, const T* lmat, int64_t 
                        b + r0, ldb, (int)m, (int)rw, (const T*)(lmat + r0 * ld + r0), ld,
                        (const T*)(ws + (r0 / SB) * (SB * SB)));
     CIMRGP_LAUNCH_CHECK(fn);
-    if (n <= r1) { pair_r0 = -1; return 0; }
+    if (n <= r1) { grp = PanelGroup(); return 0; }
     const int64_t rn = (n - r1 < CIMRGP_NB) ? (n - r1) : CIMRGP_NB;
-    if (pair_r0 < 0 && n - (r1 + rn) > pair_above) {
-        pair_r0 = r0;
-        return gemm_nt_sub<T>(b + r1, ldb, b + r0, ldb, lmat + r1 * ld + r0, ld, m, rn, (int)rw, false, st);
+    if (grp.g0 < 0) {
+        const int g = group_size(n - (r1 + rn), pair_above);
+        if (g > 1) { grp.g0 = r0; grp.left = g; }
     }
-    const int64_t kk0 = (pair_r0 >= 0) ? pair_r0 : r0;
-    pair_r0 = -1;
+    if (grp.g0 >= 0 && grp.left > 1 && n > r1 + rn) {
+        --grp.left;
+        return gemm_nt_sub<T>(b + r1, ldb, b + grp.g0, ldb, lmat + r1 * ld + grp.g0, ld, m, rn, (int)(r1 - grp.g0), false, st);
+    }
+    const int64_t kk0 = (grp.g0 >= 0) ? grp.g0 : r0;
+    grp = PanelGroup();
     return gemm_nt_sub<T>(b + r1, ldb, b + kk0, ldb, lmat + r1 * ld + kk0, ld, m, n - r1, (int)(r1 - kk0), false, st);
 }
 
@@ -655,12 +681,12 @@ static int panel_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info,
 {
     const char* fn = FACTOR ? "cimrgp_potrf" : "cimrgp_trsm_rows";
     const bool rows = (b != nullptr && m > 0);
-    int64_t pair_r0 = -1;
+    PanelGroup rows_grp;
     for (int64_t k0 = 0; k0 < n; k0 += CIMRGP_NB) {
         const int64_t w = (n - k0 < CIMRGP_NB) ? (n - k0) : CIMRGP_NB;
         const int64_t k1 = k0 + w;
         if (!FACTOR && rows) {
-            int rc = rows_panel_step<T>(b, ldb, m, kmat, ld, n, ws, k0, pair_r0, ROWS_PAIR_ABOVE_SOLVE, st, fn);
+            int rc = rows_panel_step<T>(b, ldb, m, kmat, ld, n, ws, k0, rows_grp, ROWS_PAIR_ABOVE_SOLVE, st, fn);
             if (rc) return rc;
             continue;
         }
@@ -847,10 +873,10 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     hipEvent_t ev_panel = la->ev[ne++];
     CIMRGP_HIP_TRY(hipEventRecord(ev_panel, sp), "hipEventRecord");
     hipEvent_t ev_rest = nullptr;                      // bulk update of the previous panel
-    int64_t pair_k0 = -1;                              // first panel of a pair whose far update is still owed
+    PanelGroup grp;                                    // open group of panels whose far update is still owed
     hipEvent_t ev_bulk_last = nullptr;                 // last thing queued on the bulk stream
     int64_t rows_next = 0;                             // first panel the carried rows have not seen yet
-    int64_t rows_pair_r0 = -1;                         // carried rows: first panel of a pair whose far update is owed
+    PanelGroup rows_grp;                               // carried rows: open group of panels whose far update is owed
     for (int64_t k0 = 0; k0 < n; k0 += CIMRGP_NB) {
         const int64_t w  = (n - k0 < CIMRGP_NB) ? (n - k0) : CIMRGP_NB;
         const int64_t k1 = k0 + w;
@@ -879,49 +905,52 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
         }
         if (k1 < n) {
             // bulk: lower SYRK beyond the next panel, concurrently with the chain.  While that far
-            // region is big, it is updated once per TWO panels with K = 512 (adjacent panels are
-            // adjacent columns, the same kernel applies): half the passes over C.  The first
-            // panel of a pair then only updates the columns of the panel after next ("near").
+            // region is big, it is updated once per GROUP of 2-4 panels with K = 256 x group size
+            // (adjacent panels are adjacent columns, the same kernel applies): fewer passes over C.
             ev_rest = nullptr;
             bool split_far = false;                // the split far update records its own events
             if (n > k2) {
                 CIMRGP_HIP_TRY(hipStreamWaitEvent(sb, ev_go, 0), "hipStreamWaitEvent");
                 const int64_t wnn = (n - k2 < CIMRGP_NB) ? (n - k2) : CIMRGP_NB;   // panel after next
                 const int64_t k3 = k2 + wnn;
-                if (pair_k0 < 0 && n - k3 > FAR_PAIR_ABOVE) {
-                    rc = gemm_nt_sub<T>(k + k2 * ld + k2, ld, k + k2 * ld + k0, ld, k + k2 * ld + k0, ld,
-                                        n - k2, wnn, (int)w, false, sb);
-                    if (rc) return rc;
-                    pair_k0 = k0;
-                } else if (pair_k0 >= 0 && n > k3) {
-                    // second panel of a pair: first the columns of the panel after next (all the
-                    // chain's next head update needs -- it may start as soon as they are done),
-                    // then the big remainder, which overlaps the chain's next TWO panels
-                    const int kk = (int)(k1 - pair_k0);
-                    rc = gemm_nt_sub<T>(k + k2 * ld + k2, ld, k + k2 * ld + pair_k0, ld, k + k2 * ld + pair_k0, ld,
+                if (grp.g0 < 0) {
+                    const int g = group_size(n - k3, FAR_PAIR_ABOVE);
+                    if (g > 1) { grp.g0 = k0; grp.left = g; }
+                }
+                if (grp.g0 >= 0) {
+                    // a panel of a group: the columns of the panel after next with all the group's
+                    // panels so far (all the chain's next head update needs -- it may start as soon
+                    // as they are done) ...
+                    const int kk = (int)(k1 - grp.g0);
+                    rc = gemm_nt_sub<T>(k + k2 * ld + k2, ld, k + k2 * ld + grp.g0, ld, k + k2 * ld + grp.g0, ld,
                                         n - k2, wnn, kk, false, sb);
                     if (rc) return rc;
                     ev_rest = la->ev[ne++];
                     CIMRGP_HIP_TRY(hipEventRecord(ev_rest, sb), "hipEventRecord");
-                    const double mm = (double)(n - k3);
-                    TrailRec* rec = rec_open(sb, mm * (mm + 1.0) * (double)kk);
-                    rc = gemm_nt_sub<T>(k + k3 * ld + k3, ld, k + k3 * ld + pair_k0, ld, k + k3 * ld + pair_k0, ld,
-                                        n - k3, n - k3, kk, true, sb);
-                    if (rec) (void)hipEventRecord(rec->stop, sb);
-                    if (rc) return rc;
-                    pair_k0 = -1;
-                    ev_bulk_last = la->ev[ne++];
-                    CIMRGP_HIP_TRY(hipEventRecord(ev_bulk_last, sb), "hipEventRecord");
+                    ev_bulk_last = ev_rest;
                     split_far = true;
+                    if (--grp.left == 0 || n <= k3) {
+                        // ... and, closing the group, the big remainder with K = 256 x group size,
+                        // which overlaps the chain's next panels
+                        if (n > k3) {
+                            const double mm = (double)(n - k3);
+                            TrailRec* rec = rec_open(sb, mm * (mm + 1.0) * (double)kk);
+                            rc = gemm_nt_sub<T>(k + k3 * ld + k3, ld, k + k3 * ld + grp.g0, ld, k + k3 * ld + grp.g0, ld,
+                                                n - k3, n - k3, kk, true, sb);
+                            if (rec) (void)hipEventRecord(rec->stop, sb);
+                            if (rc) return rc;
+                            ev_bulk_last = la->ev[ne++];
+                            CIMRGP_HIP_TRY(hipEventRecord(ev_bulk_last, sb), "hipEventRecord");
+                        }
+                        grp = PanelGroup();
+                    }
                 } else {
-                    const int64_t kk0 = (pair_k0 >= 0) ? pair_k0 : k0;
                     const double mm = (double)(n - k2);
-                    TrailRec* rec = rec_open(sb, mm * (mm + 1.0) * (double)(k1 - kk0));
-                    rc = gemm_nt_sub<T>(k + k2 * ld + k2, ld, k + k2 * ld + kk0, ld, k + k2 * ld + kk0, ld,
-                                        n - k2, n - k2, (int)(k1 - kk0), true, sb);
+                    TrailRec* rec = rec_open(sb, mm * (mm + 1.0) * (double)w);
+                    rc = gemm_nt_sub<T>(k + k2 * ld + k2, ld, k + k2 * ld + k0, ld, k + k2 * ld + k0, ld,
+                                        n - k2, n - k2, (int)w, true, sb);
                     if (rec) (void)hipEventRecord(rec->stop, sb);
                     if (rc) return rc;
-                    pair_k0 = -1;
                 }
                 if (!split_far) {
                     ev_rest = la->ev[ne++];
@@ -943,7 +972,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
                 if (sq != st) CIMRGP_HIP_TRY(hipStreamWaitEvent(sq, ev_final, 0), "hipStreamWaitEvent");
                 // (pairing the rows' updates below that size was measured neutral-to-worse at N = 8192)
                 for (int64_t r0 = rows_next; r0 <= k0; r0 += CIMRGP_NB) {
-                    rc = rows_panel_step<T>(b, ldb, m, k, ld, n, ws, r0, rows_pair_r0, FAR_PAIR_ABOVE, sq, "cimrgp_potrf_rows");
+                    rc = rows_panel_step<T>(b, ldb, m, k, ld, n, ws, r0, rows_grp, FAR_PAIR_ABOVE, sq, "cimrgp_potrf_rows");
                     if (rc) return rc;
                 }
                 rows_next = k1;

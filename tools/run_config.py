@@ -50,23 +50,34 @@ def main():
     kernels = [ca.RBFKernel(l=1.0 / 2 ** j, sf=1.0, noise=0.01) for j in range(res + 1)]
     idx = ca.IndexSetUniform(n, res, 2)
     idx_t = ca.IndexSetUniform(ns, res, 2)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    model = ca.MultiResolutionGaussianProcess([x, y], index_set_obj=idx, spectral_density_obj=kernels,
-                                              dtype=args.dtype, keep_factors=True)
-    model.fit()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    mean, var = model.get_predicted_mean_and_var(xs, idx_t)
-    torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    nblocks = sum(model.n_regions)
+    # two passes: the first pays for tens of GB of fresh device allocations (hipMalloc + first
+    # touch, seconds and erratic), the second reuses torch's cached blocks and is the one reported
+    cold = None
+    for attempt in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model = ca.MultiResolutionGaussianProcess([x, y], index_set_obj=idx, spectral_density_obj=kernels,
+                                                  dtype=args.dtype, keep_factors=True)
+        model.fit()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        mean, var = model.get_predicted_mean_and_var(xs, idx_t)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        if attempt == 0:
+            cold = (t1 - t0, t2 - t1)
+            f_bar = model._f_bar_final.cpu().numpy()
+            n_regions, n_samps = model.n_regions, model.n_samps
+            del model
+    model_f_bar = f_bar
+    nblocks = sum(n_regions)
     out = dict(config=args.config, n=n, layers=res + 1, blocks=nblocks, dtype=args.dtype,
-               fit_s=t1 - t0, predict_s=t2 - t1, posteriors_per_s=nblocks / (t2 - t0),
-               cholesky_flops=float(sum(sum(float(m) ** 3 / 3 for m in layer) for layer in model.n_samps)),
+               fit_s=t1 - t0, predict_s=t2 - t1, fit_s_cold=cold[0], predict_s_cold=cold[1],
+               posteriors_per_s=nblocks / (t2 - t0),
+               cholesky_flops=float(sum(sum(float(m) ** 3 / 3 for m in layer) for layer in n_samps)),
                mean_finite=bool(np.isfinite(mean).all()), var_finite=bool(np.isfinite(var).all()),
                var_min=float(var.min()), var_max=float(var.max()),
-               train_rmse=float(np.sqrt(np.mean((model._f_bar_final.cpu().numpy() - y) ** 2))),
+               train_rmse=float(np.sqrt(np.mean((model_f_bar - y) ** 2))),
                peak_mem_GiB=torch.cuda.max_memory_allocated() / 2 ** 30)
     if args.check:
         import oracle
