@@ -78,6 +78,7 @@ constexpr int SB = 64;   // diagonal sub-block
 // end-to-end time (longer-lived update workgroups, longer slot waits of the chain), so it
 // starts above that size.
 constexpr int64_t FAR_PAIR_ABOVE = 8192;
+constexpr int64_t SINGLE_TAIL_BELOW = 4864;  // trailing matrix at or below this: finish on one queue (see potrf_run)
 constexpr int64_t HEAD_FIRST_ABOVE = 4608;   // the bulk update waits for the head update while the trailing matrix is larger
 constexpr int64_t ROWS_PAIR_ABOVE_SOLVE = 1024;   // stand-alone row-wise solve: pair the updates while more columns remain
 constexpr int64_t ROWS_START_BELOW = 4608;   // carried rows start once the trailing matrix is smaller than this
@@ -846,7 +847,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     const bool rows = (b != nullptr && m > 0);
     CIMRGP_HIP_TRY(hipMemsetAsync(info, 0, sizeof(int32_t), st), "hipMemsetAsync(info)");
     const int64_t npanels = (n + CIMRGP_NB - 1) / CIMRGP_NB;
-    LookAhead* la = (npanels > 2) ? lookahead_ctx((size_t)(6 * npanels + 8)) : nullptr;
+    LookAhead* la = (npanels > 2) ? lookahead_ctx((size_t)(7 * npanels + 8)) : nullptr;
     if (la == nullptr) {
         int rc0 = panel_sweep<T, true>(k, n, ld, ws, info, b, m, ldb, st);
         return rc0 ? rc0 : build_invT<T>(k, n, ld, ws, st);
@@ -874,12 +875,70 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     CIMRGP_HIP_TRY(hipEventRecord(ev_panel, sp), "hipEventRecord");
     hipEvent_t ev_rest = nullptr;                      // bulk update of the previous panel
     PanelGroup grp;                                    // open group of panels whose far update is still owed
+    auto grp_open = [&]() { return grp.g0 >= 0; };
+    bool tail_done = false;
+    const int64_t single_tail_below = SINGLE_TAIL_BELOW;
     hipEvent_t ev_bulk_last = nullptr;                 // last thing queued on the bulk stream
     int64_t rows_next = 0;                             // first panel the carried rows have not seen yet
     PanelGroup rows_grp;                               // carried rows: open group of panels whose far update is owed
+    // Panel k0 is final (event ev_final): solve + update the carried rows.  They form their own
+    // chain (panel p+1 of the rows needs panel p of the rows) that depends on the factorisation
+    // only through "panel k0 final", so it runs on a third queue and lags behind: nothing of it is
+    // issued while the trailing updates are still large (that phase is MFMA-bound and the rows
+    // would only take compute units away from the critical path); from then on it fills the
+    // compute units the latency-bound panel chain leaves idle.
+    auto rows_after_panel = [&](int64_t k0, int64_t k1, hipEvent_t ev_final) -> int {
+        if (!rows) return 0;
+        hipStream_t sq = la->rows ? la->rows : st;
+        const bool defer = (sq != st) && (n - k1 > ROWS_START_BELOW) && (k1 < n);
+        if (defer) return 0;
+        if (sq != st) CIMRGP_HIP_TRY(hipStreamWaitEvent(sq, ev_final, 0), "hipStreamWaitEvent");
+        // (pairing the rows' updates below that size was measured neutral-to-worse at N = 8192)
+        for (int64_t r0 = rows_next; r0 <= k0; r0 += CIMRGP_NB) {
+            int rcr = rows_panel_step<T>(b, ldb, m, k, ld, n, ws, r0, rows_grp, FAR_PAIR_ABOVE, sq, "cimrgp_potrf_rows");
+            if (rcr) return rcr;
+        }
+        rows_next = k1;
+        return 0;
+    };
     for (int64_t k0 = 0; k0 < n; k0 += CIMRGP_NB) {
         const int64_t w  = (n - k0 < CIMRGP_NB) ? (n - k0) : CIMRGP_NB;
         const int64_t k1 = k0 + w;
+        if (!rows && k1 < n && n - k1 <= single_tail_below && !grp_open()) {
+            // ---- single-stream tail.  Once the trailing matrix is small the look-ahead no longer
+            // pays: its chain kernels wait for slots beside the update and every panel costs an
+            // inter-queue hop, while one queue runs 4 x (diag + solve) = 124 us plus ONE update of
+            // everything right of the panel, all at full speed (measured whole potrf, single queue
+            // vs look-ahead: n = 2048: 1.23 vs 1.37 ms, 4096: 2.80 vs 3.04, 6144: 4.84 vs 5.05,
+            // 8192: 7.95 vs 7.73; hybrid at N = 8192: 7.86 -> 7.52 ms).  With carried rows the rows'
+            // own queue fills the tail either way and the hybrid is neutral (9.69 vs 9.73 ms): not
+            // used then.  Panel k0 is factored; the region right of it holds all earlier
+            // panels' updates once the bulk queue has drained.
+            CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0), "hipStreamWaitEvent");
+            if (sb != st && ev_bulk_last) CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_bulk_last, 0), "hipStreamWaitEvent");
+            hipEvent_t ev_fin = ev_panel;
+            for (int64_t p0 = k0; p0 < n; p0 += CIMRGP_NB) {
+                const int64_t pw = (n - p0 < CIMRGP_NB) ? (n - p0) : CIMRGP_NB;
+                const int64_t p1 = p0 + pw;
+                rc = rows_after_panel(p0, p1, ev_fin);
+                if (rc) return rc;
+                if (p1 >= n) break;
+                const double mm = (double)(n - p1);
+                TrailRec* rec = rec_open(st, mm * (mm + 1.0) * (double)pw);
+                rc = gemm_nt_sub<T>(k + p1 * ld + p1, ld, k + p1 * ld + p0, ld, k + p1 * ld + p0, ld,
+                                    n - p1, n - p1, (int)pw, true, st);
+                if (rec) (void)hipEventRecord(rec->stop, st);
+                if (rc) return rc;
+                rc = factor_panel<T>(k, n, ld, ws, info, p1, (n - p1 < CIMRGP_NB) ? (n - p1) : CIMRGP_NB, st);
+                if (rc) return rc;
+                if (rows && la->rows) {
+                    ev_fin = la->ev[ne++];
+                    CIMRGP_HIP_TRY(hipEventRecord(ev_fin, st), "hipEventRecord");
+                }
+            }
+            tail_done = true;
+            break;
+        }
         const hipEvent_t ev_final = ev_panel;          // panel k0 is final (recorded on the side stream)
         hipEvent_t ev_go = ev_panel;                   // what the bulk stream waits for: panel k0 final ...
         const int64_t wn = (k1 < n) ? ((n - k1 < CIMRGP_NB) ? (n - k1) : CIMRGP_NB) : 0;   // next panel
@@ -959,25 +1018,8 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
                 }
             }
         }
-        if (rows) {
-            // Panel k0 is final: solve + update the carried rows.  They form their own chain (panel
-            // p+1 of the rows needs panel p of the rows) that depends on the factorisation only
-            // through "panel k0 final", so it runs on a third queue and lags behind: nothing of it
-            // is issued while the trailing updates are still large (that phase is MFMA-bound and
-            // the rows would only take compute units away from the critical path); from then on it
-            // fills the compute units the latency-bound panel chain leaves idle.
-            hipStream_t sq = la->rows ? la->rows : st;
-            const bool defer = (sq != st) && (n - k1 > ROWS_START_BELOW) && (k1 < n);
-            if (!defer) {
-                if (sq != st) CIMRGP_HIP_TRY(hipStreamWaitEvent(sq, ev_final, 0), "hipStreamWaitEvent");
-                // (pairing the rows' updates below that size was measured neutral-to-worse at N = 8192)
-                for (int64_t r0 = rows_next; r0 <= k0; r0 += CIMRGP_NB) {
-                    rc = rows_panel_step<T>(b, ldb, m, k, ld, n, ws, r0, rows_grp, FAR_PAIR_ABOVE, sq, "cimrgp_potrf_rows");
-                    if (rc) return rc;
-                }
-                rows_next = k1;
-            }
-        }
+        rc = rows_after_panel(k0, k1, ev_final);
+        if (rc) return rc;
     }
     if (rows && la->rows) {
         hipEvent_t ev_rows_done = la->ev[ne++];
@@ -985,8 +1027,10 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
         CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_rows_done, 0), "hipStreamWaitEvent");
     }
     // join: the last panel (side stream); every bulk update precedes it through the chain's waits
-    CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0), "hipStreamWaitEvent");
-    if (sb != st && ev_bulk_last) CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_bulk_last, 0), "hipStreamWaitEvent");
+    if (!tail_done) {
+        CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0), "hipStreamWaitEvent");
+        if (sb != st && ev_bulk_last) CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_bulk_last, 0), "hipStreamWaitEvent");
+    }
     return build_invT<T>(k, n, ld, ws, st);
 }
 
