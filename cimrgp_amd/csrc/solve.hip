@@ -18,7 +18,6 @@ namespace {
 constexpr int SB   = 64;
 #endif
 constexpr int MAXQ = 8;
-constexpr int LSI  = SB + 1;
 
 // (n x q) row-major  <->  (q x n)
 template <typename T>
