@@ -1,10 +1,11 @@
-"""Input holder / per-block gather and the learned input warp (reference Inputs.py:8-60).
+"""Input holder, per-block view and the learned input warp (reference Inputs.py:8-60).
 
-Regions are contiguous sample ranges, so ``get_inputs`` is a slice -- on the device a pointer
-offset, never a gather kernel.  With ``learn_inputs=True`` the inputs are warped onto a regular
-grid z = linspace(min x, max x, N) by an exact RBF GP x -> z (Inputs.py:11-22), which is the
-only caller of the dense GP inside the reference; above 3000 samples the reference fits that GP
-on a 3000-point subsample (Inputs.py:23-48) -- reproduced here, with the HIP-backed ``GP_RBF``.
+Regions are contiguous sample ranges, so a block's inputs are a slice -- on the device a pointer
+offset, never a gather kernel.  With ``learn_inputs=True`` the inputs are replaced by a regular
+grid z = linspace(min x, max x, N) and an exact RBF GP x -> z is kept for warping test inputs
+(the only place the reference itself calls a dense GP); above 3000 samples the reference fits
+that GP on a random subsample -- one point per block of a 2-layer uniform index set, topped up to
+3000 -- which is reproduced with the same random draws, on the HIP-backed ``GP_RBF``.
 """
 import random
 
@@ -12,55 +13,71 @@ import numpy as np
 
 from .IndexSetGenerator import IndexSetUniform
 
+#: sample count up to which the warp GP is fitted on everything (Inputs.py:20)
+WARP_FULL_FIT_MAX = 3000
+
+
+def _grid_like(values):
+    """Regular grid over the range of ``values`` with as many points (Inputs.py:12,16)."""
+    return np.linspace(np.min(values), np.max(values), values.shape[0])[:, None]
+
+
+def _divider_for(n_samps, rate):
+    """Number of blocks the subsample draws one point from: rate x n, with the rate scaled down
+    by 10 per decade of n above 10^4 (Inputs.py:62-71)."""
+    decades = 0 if n_samps < 10000 else (1 if n_samps < 100000 else (2 if n_samps < 1000000 else 3))
+    return int(np.floor(rate * 10.0 ** (-decades) * n_samps))
+
+
+def _subsample_ids(n_samps):
+    """Indices of the reference's warp subsample (Inputs.py:23-42), same draw order: the block
+    count from ``random.uniform``, one ``np.random.permutation`` per block, one for the top-up."""
+    blocks = IndexSetUniform(sample_length=n_samps, resolution=1,
+                             divider=_divider_for(n_samps, random.uniform(.1, .2))).index_set[-1]
+    picked = [int(np.random.permutation(np.asarray(blk))[0]) for blk in blocks]
+    missing = WARP_FULL_FIT_MAX - len(picked)
+    if missing > 0:
+        pool = np.delete(np.arange(n_samps), picked)
+        picked = list(np.random.permutation(pool)[:missing]) + picked
+    return np.unique(picked)
+
 
 class Inputs(object):
     def __init__(self, x, index_set, learn_inputs=False, full_x=None, input_model=None, model_factory=None):
-        """``x``: (N x d) NumPy array (already normalised by the caller, MRGP.py:69).
-        ``model_factory``: callable returning a fresh ``RegressionMethod`` (default: the HIP
-        ``GP_RBF`` with the optimisation step, as the reference's ``GP_RBF()``)."""
+        """``x``: (N x d) NumPy array, already normalised by the caller (MRGP.py:69).
+        ``model_factory``: callable returning a fresh ``RegressionMethod``; default: the HIP
+        ``GP_RBF`` with its hyper-parameter optimisation, the counterpart of the reference's
+        ``GP_RBF()``."""
         self.learn_inputs = learn_inputs
         self.index_set = index_set
-        if self.learn_inputs is True:
-            if model_factory is None:
-                from .RegressionInput import GP_RBF
-                model_factory = lambda: GP_RBF(optimize=True)
-            z = np.atleast_2d(np.linspace(start=np.min(x), stop=np.max(x), num=x.shape[0])).T
-            if full_x is None:
-                train_data = [x, z]
-            else:
-                z_full = np.atleast_2d(np.linspace(start=np.min(full_x), stop=np.max(full_x),
-                                                   num=full_x.shape[0])).T
-                train_data = [full_x, z_full]
-            if input_model is None:
-                if train_data[0].shape[0] < 3001:
-                    self.input_model = model_factory()
-                    self.input_model.fit(train_data)
-                else:
-                    n_samps = train_data[0].shape[0]
-                    n_repeats = 1
-                    min_length = 3000
-                    n_divide = self._get_best_divider(n_samps, rate=random.uniform(.1, .2))
-                    regions = IndexSetUniform(sample_length=n_samps, resolution=1, divider=n_divide).index_set[-1]
-                    ids_all = np.arange(n_samps)
-                    self.input_model = []
-                    for _ in range(n_repeats):
-                        ids_l = [int(np.random.permutation(np.asarray(r))[0]) for r in regions]
-                        if min_length > len(ids_l):
-                            rem_ids = np.delete(ids_all, ids_l)
-                            ids_rep = list(np.random.permutation(rem_ids)[0:min_length - len(ids_l)]) + ids_l
-                        else:
-                            ids_rep = ids_l
-                        ids = np.sort(np.unique(ids_rep))
-                        model = model_factory()
-                        model.fit([train_data[0][ids, :], train_data[1][ids, :]])
-                        self.input_model.append(model)
-            else:
-                self.input_model = input_model
-            self.z = train_data[1]
-            self.x = z
-        else:
-            self.input_model = input_model
-            self.x = x
+        self.input_model = input_model
+        self.x = x
+        if learn_inputs is not True:
+            return
+        source = x if full_x is None else full_x
+        target = _grid_like(source)
+        if input_model is None:
+            self.input_model = self._fit_warp(source, target, model_factory)
+        self.z = target                      # the grid of full_x when that was given (Inputs.py:52)
+        self.x = _grid_like(x)
+
+    @staticmethod
+    def _fit_warp(source, target, model_factory):
+        if model_factory is None:
+            from .RegressionInput import GP_RBF
+            model_factory = lambda: GP_RBF(optimize=True)
+        n_samps = source.shape[0]
+        if n_samps <= WARP_FULL_FIT_MAX:
+            model = model_factory()
+            model.fit([source, target])
+            return model
+        models = []
+        for _ in range(1):                   # the reference's n_repeats = 1: a one-member ensemble
+            ids = _subsample_ids(n_samps)
+            model = model_factory()
+            model.fit([source[ids, :], target[ids, :]])
+            models.append(model)
+        return models
 
     def get_inputs(self, resolution, region):
         a, b = self.index_set.bounds[resolution][region]
@@ -79,12 +96,4 @@ class Inputs(object):
 
     @staticmethod
     def _get_best_divider(n_samps, rate=0.2):
-        if n_samps < 10000:
-            factor = 1 * rate
-        elif n_samps < 100000:
-            factor = 1e-1 * rate
-        elif n_samps < 1000000:
-            factor = 1e-2 * rate
-        else:
-            factor = 1e-3 * rate
-        return int(np.floor(factor * n_samps))
+        return _divider_for(n_samps, rate)
