@@ -9,6 +9,7 @@ partition (weak scaling) and the per-step predictions are summed with ONE
 all-reduce of the fused [mean | var] buffer (RCCL over xGMI).
 
     python bench.py --gpus 1 --steps 10 --warmup 2
+    python bench.py --gpus N ...          # WORLD_SIZE unset: spawns its own N ranks (see launch_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 """
@@ -16,6 +17,8 @@ import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,32 +32,78 @@ FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X FP64 matrix peak (spec)
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32-input MFMA peak
 
 
+import workloads
+
+
 def make_block(n, q, seed):
-    """x ~ sorted U(-sqrt3, sqrt3), y_k = sin(3x+k) + 0.5 sin(17x^2) + 0.1 N(0,1)."""
-    rng = np.random.default_rng(seed)
-    x = np.sort(rng.uniform(-np.sqrt(3), np.sqrt(3), size=(n, 1)), axis=0)
-    y = np.hstack([np.sin(3 * x + k) + 0.5 * np.sin(17 * x * x) for k in range(q)]) + 0.1 * rng.normal(size=(n, q))
-    return x, y
+    """SURVEY.md 8d config 2 (workloads.make_block): x ~ sorted U(-sqrt3, sqrt3),
+    y_k = sin(3x+k) + 0.5 sin(17x^2) + 0.1 N(0,1)."""
+    return workloads.make_block(n, q, seed)
 
 
-def cpu_baseline(n, ns, q, ell, sf2, noise, seed):
-    """The oracle (NumPy/SciPy port) timed on the host cores on ONE posterior of the same
-    workload -- a reported baseline, never the product path."""
-    import oracle
-    x, y = make_block(n, q, seed)
-    xs = np.linspace(-1.7, 1.7, ns)[:, None]
-    t0 = time.perf_counter()
-    fit = oracle.block_fit(x, y, ell, sf2, noise)
-    oracle.block_predict(x, fit, xs, ell, sf2, True)
-    dt = time.perf_counter() - t0
+def _host_description():
+    """CPU model, thread count and BLAS build of the box the baseline is timed on."""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    blas, threads = "unknown", os.cpu_count() or 1
     try:
         from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count() or 1])
+        pools = [p for p in threadpool_info() if p.get("user_api") == "blas"]
+        if pools:
+            threads = max(p.get("num_threads", 1) for p in pools)
+            blas = "; ".join("%s %s (%s, %s)" % (p.get("internal_api"), p.get("version"), p.get("threading_layer", "?"),
+                                                 p.get("architecture", "?")) for p in pools)
     except Exception:
-        cores = os.cpu_count() or 1
-    return dict(value=1.0 / dt, unit="posteriors/s", cores=int(cores), kind="port",
-                sample="1 posterior (Gram+Cholesky+solve+mean/var at N/4 points) of the N=%d block, "
-                       "NumPy/SciPy FP64, %.1f s" % (n, dt))
+        pass
+    return model, int(threads), blas
+
+
+def cpu_baseline(n, ns, q, ell, sf2, noise, seed, warmups=3, repeats=5):
+    """The oracle (NumPy/SciPy port) timed on the host cores on complete posteriors of the same
+    workload: ``warmups`` untimed runs, then the median of ``repeats``.  A reported
+    baseline, never the product path.  Also returns the oracle's outputs: bench.py checks the GPU
+    step against them at full size."""
+    import oracle
+    x, y = make_block(n, q, seed)
+    xs = workloads.block_test_points(ns)
+    times = []
+    for it in range(warmups + repeats):
+        t0 = time.perf_counter()
+        fit = oracle.block_fit(x, y, ell, sf2, noise)
+        omean, ovar = oracle.block_predict(x, fit, xs, ell, sf2, True)
+        dt = time.perf_counter() - t0
+        if it >= warmups:
+            times.append(dt)
+    med = float(np.median(times))
+    model, threads, blas = _host_description()
+    rec = dict(value=1.0 / med, unit="posteriors/s", cores=threads, kind="port",
+               sample="%d warm-ups + median of %d complete posteriors (Gram + Cholesky + solves + mean/var at N/4 "
+                      "points) of the N=%d block, NumPy/SciPy FP64: %.2f s each (min %.2f, max %.2f)"
+                      % (warmups, repeats, n, med, min(times), max(times)),
+               cpu_model=model, blas=blas, seconds_per_posterior=med)
+    return rec, omean, ovar
+
+
+def launch_ranks(args):
+    """``python bench.py --gpus N`` without a launcher: start N ranks as children of
+    ``torch.distributed.run`` BEFORE this process has made any GPU call (it never makes one), hand
+    them the same flags, pass their output through and exit with their status."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -65,7 +114,12 @@ def main():
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-warmups", type=int, default=3)
+    ap.add_argument("--cpu-repeats", type=int, default=5)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
 
     import torch
     import torch.distributed as td
@@ -95,7 +149,7 @@ def main():
     x, y = make_block(n, q, 1234 + rank)
     xd = dev.to_device(x, tdt, device)
     yd = dev.to_device(y, tdt, device)
-    xsd = dev.to_device(np.linspace(-1.7, 1.7, ns)[:, None], tdt, device)
+    xsd = dev.to_device(workloads.block_test_points(ns), tdt, device)
 
     # buffers allocated once: the step itself never allocates the big matrices
     kbuf = dev.alloc_matrix(n, n, tdt, device)
@@ -154,6 +208,8 @@ def main():
                "cimrgp_profile_collect")
     for i in range(5):
         stage_ms[i] = ev[i].elapsed_time(ev[i + 1])
+    last_mean = mean.double().cpu().numpy()                    # the last timed step's outputs (this rank)
+    last_var = fused[q, rank * ns:(rank + 1) * ns].double().cpu().numpy()
     # Cholesky alone (no carried rows) for the effective-GFLOP/s figure, timed separately
     torch.cuda.synchronize()
     chol_ms = []
@@ -217,8 +273,18 @@ def main():
             mm = [n - 256 * (p + 2) for p in range((n // 256) - 2)]
             out["roofline"]["algorithmic_bytes_per_launch"] = float(np.mean([m * (m + 1) / 2 * 8 * 2 + m * 256 * 8 for m in mm]))
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, ns, q, ell, sf2, noise, 1234)
+            rec, omean, ovar = cpu_baseline(n, ns, q, ell, sf2, noise, 1234, args.cpu_warmups, args.cpu_repeats)
+            out["cpu_baseline"] = rec
+            # full-size parity of the headline config: the last timed step against the oracle's
+            # posterior on the same arrays (north_star: 1e-5 relative on mean and variance, max
+            # error over max magnitude as in tests/)
+            out["parity_rel_err_mean"] = float(np.max(np.abs(last_mean - omean)) / np.max(np.abs(omean)))
+            out["parity_rel_err_var"] = float(np.max(np.abs(last_var - ovar)) / np.max(np.abs(ovar)))
+            out["parity_ok"] = bool(out["parity_rel_err_mean"] <= 1e-5 and out["parity_rel_err_var"] <= 1e-5)
         print(json.dumps(out))
+        if out.get("parity_ok") is False:
+            raise SystemExit("bench.py: the GPU posterior differs from the oracle by more than 1e-5: mean %.3e var %.3e"
+                             % (out["parity_rel_err_mean"], out["parity_rel_err_var"]))
     if world > 1:
         td.destroy_process_group()
 

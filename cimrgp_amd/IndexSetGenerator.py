@@ -13,7 +13,7 @@ import numpy as np
 
 class IndexSetUniform(object):
     def __init__(self, sample_length, resolution, divider, n_regions=None,
-                 min_percentage_of_samples_per_region=None):
+                 min_percentage_of_samples_per_region=None, first_divider_power=0):
         """
         :param sample_length: number of samples
         :param resolution: number of layers minus one
@@ -24,10 +24,21 @@ class IndexSetUniform(object):
             ``divider`` is ignored
         :param min_percentage_of_samples_per_region: rejection threshold for the
             random regions, default 25% of the average region size
+        :param first_divider_power: ROOT-BLOCK POLICY (not in the reference, default 0 =
+            the reference): layer m is cut into ``divider**(m + first_divider_power)``
+            regions, so the hierarchy starts at a layer whose regions fit one device
+            instead of at the single all-samples region.  The reference allows a
+            multi-region layer 0 only through ``n_regions=[...]``
+            (IndexSetGenerator.py:28-43) and assumes one root region when it sizes
+            the latent function (``n_samps_0 = len(index_set[0][0])``, Stats.py:127);
+            this package sizes it by ``sample_length``.
         """
         self.resolution = int(resolution)
+        self.first_divider_power = int(first_divider_power)
+        if self.first_divider_power < 0:
+            raise ValueError('first_divider_power must be >= 0')
         if n_regions is None:
-            self.divider = 0 if self.resolution == 0 else int(divider)
+            self.divider = 0 if (self.resolution == 0 and self.first_divider_power == 0) else int(divider)
         self.sample_length = int(sample_length)
         self.bounds = []
         if n_regions is None:
@@ -56,7 +67,7 @@ class IndexSetUniform(object):
         return [len(layer) for layer in self.bounds]
 
     def _uniform_bounds(self, resolution):
-        n_regions = int(np.power(self.divider, resolution))
+        n_regions = int(np.power(self.divider, resolution + self.first_divider_power))
         per_region = self.sample_length // n_regions
         if per_region < 1:
             raise ValueError('*** Chosen resolution is too large! ***')

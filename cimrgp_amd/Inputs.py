@@ -42,6 +42,52 @@ def _subsample_ids(n_samps):
     return np.unique(picked)
 
 
+def space_filling_order(x, bits=16):
+    """Permutation that sorts (N x d) inputs along a space-filling curve, so that the
+    CONTIGUOUS index ranges of an ``IndexSetUniform`` are spatially compact regions.
+
+    The reference partitions by sample order only (``x[T_jl, :]``, Inputs.py:57-60): whatever
+    order the caller's samples arrive in defines the regions.  For 1-D inputs sorting gives
+    intervals; for d = 2 this helper gives the Hilbert-curve order (any contiguous range of a
+    Hilbert order is a connected, compact patch; aligned power-of-two ranges are squares),
+    for d > 2 the Morton (Z-order) interleave.  Train and test points must be ordered with the
+    same call; predictions come back in the sorted order (``out[perm] = pred`` undoes it).
+    """
+    x = np.asarray(x, dtype=np.float64)
+    if x.ndim != 2:
+        raise ValueError('inputs must be (N x d)')
+    n, d = x.shape
+    if d == 1:
+        return np.argsort(x[:, 0], kind='stable')
+    lo, hi = x.min(axis=0), x.max(axis=0)
+    span = np.where(hi > lo, hi - lo, 1.0)
+    side = 1 << int(bits)
+    cells = np.minimum(((x - lo) / span * side).astype(np.int64), side - 1)
+    if d == 2:
+        # Hilbert index of cell (cx, cy), iterative quadrant rotation from the top bit down
+        cx, cy = cells[:, 0].copy(), cells[:, 1].copy()
+        key = np.zeros(n, dtype=np.int64)
+        s = side >> 1
+        while s > 0:
+            rx = ((cx & s) > 0).astype(np.int64)
+            ry = ((cy & s) > 0).astype(np.int64)
+            key += s * s * ((3 * rx) ^ ry)
+            flip = (ry == 0) & (rx == 1)
+            cx = np.where(flip, side - 1 - cx, cx)
+            cy = np.where(flip, side - 1 - cy, cy)
+            swap = ry == 0
+            cx, cy = np.where(swap, cy, cx), np.where(swap, cx, cy)
+            s >>= 1
+        return np.argsort(key, kind='stable')
+    per_dim = max(1, min(int(bits), 62 // d))
+    cells >>= (int(bits) - per_dim)
+    key = np.zeros(n, dtype=np.int64)
+    for b in range(per_dim):
+        for k in range(d):
+            key |= ((cells[:, k] >> b) & 1) << (b * d + (d - 1 - k))
+    return np.argsort(key, kind='stable')
+
+
 class Inputs(object):
     def __init__(self, x, index_set, learn_inputs=False, full_x=None, input_model=None, model_factory=None):
         """``x``: (N x d) NumPy array, already normalised by the caller (MRGP.py:69).

@@ -195,18 +195,28 @@ class MultiResolutionGaussianProcess(object):
         self._fit()
 
     def _fit(self):
+        n, q = self._y.shape
         f_bar = torch.zeros_like(self._y)
         for j in range(self.n_layers):
             self._f_bar_layers[j] = f_bar
-            layer_pred = torch.zeros_like(self._y)
+            # [layer's training-point prediction (N x q) | failure flag]: ONE buffer, one collective
+            buf = torch.zeros(n * q + 1, dtype=self.dtype, device=self.device)
+            layer_pred = buf[:n * q].view(n, q)
             owned = self._owned(j)
             self.posterior_obj[j].update_scale_given_axis(
                 y_mean=self._slices(self._y, j), x=self.x[j], f_bar=self._slices(f_bar, j),
                 train_out=self._slices(layer_pred, j), owned=owned, keep_factors=self.keep_factors)
-            self.posterior_obj[j].check(owned)
+            # A non-PD block must fail on EVERY rank, not only on its owner (whose exception
+            # would leave the others blocked in the collective): the blocks' LAPACK-style info
+            # words ride in the same all-reduce and every rank raises after it.
+            self.posterior_obj[j].failure_flag(owned, out=buf[n * q:])
             # residual chain (Stats.py:126-157): every rank needs the whole layer's prediction
-            dist.allreduce_sum_(layer_pred, self.group)
+            dist.allreduce_sum_(buf, self.group)
             f_bar = f_bar + layer_pred
+            if float(buf[n * q].item()) != 0.0:
+                self.posterior_obj[j].check(owned)           # the owner reports the leading minor
+                raise np.linalg.LinAlgError('Matrix is not positive definite (a block of layer %d '
+                                            'owned by another rank)' % j)
         self._f_bar_final = f_bar
         self._fitted = True
 
@@ -244,7 +254,10 @@ class MultiResolutionGaussianProcess(object):
         mean = torch.zeros((ns, self.dy), dtype=self.dtype, device=self.device)
         var = fused[self.dy] if want_var else None
         if index_set is None:
-            # every prediction is taken from resolution 0 (MRGP.py:726-755)
+            # every prediction is taken from resolution 0 (MRGP.py:726-755), which presumes ONE
+            # root region; with a multi-region first layer the test points need an index set
+            if self.n_regions[0] != 1:
+                raise ValueError('index_set_obj is required when the first layer has more than one region')
             if self.owner[0][0] == self.rank:
                 self.posterior_obj[0].blocks[0].predict(xs, mean, var)
         else:

@@ -127,6 +127,14 @@ class DensePosterior(object):
         total = sum(int(v.shape[0]) for v in views)
         return torch.as_strided(base, (total, base.shape[1]), base.stride())
 
+    def failure_flag(self, regions, out):
+        """out[0] = largest LAPACK ``info`` over ``regions`` (0 = all factorisations fine), written
+        on the device without a host synchronisation."""
+        infos = [self.blocks[l].info for l in regions if self.blocks[l] is not None and self.blocks[l].info is not None]
+        if infos:
+            out.copy_(torch.stack([i.reshape(()) for i in infos]).max().to(out.dtype).reshape(1))
+        return out
+
     def check(self, regions=None):
         """Raise ``numpy.linalg.LinAlgError`` if any factorisation met a non-positive pivot."""
         for l in (range(self.n_regions) if regions is None else regions):

@@ -883,14 +883,17 @@ class ReducedRankMRGP(MultiResolutionGaussianProcess):
             targets = {l: self._y[int(self.index_set_obj.bounds[j][l][0]):int(self.index_set_obj.bounds[j][l][1])]
                        for l in owned}
             y_var = [0.0] * self.n_regions[j]
-            mom = self._moments(j, owned, targets)
-            po.update_scale_given_axis(mom, pr, st, spectral_density=self.spectral_density_prior[j], regions=owned)
-            po.update_axis(pr, po, st, regions=owned)
-            st.update_axis(po, regions=owned)
-            st.update_scale(po, st, regions=owned)
-            po.update_ard(pr, st, self.spectral_density_prior[j], regions=owned)
-            st.update_ard(po, regions=owned)
-            mom = self._moments(j, owned, targets)                     # residuals under the new E[au]
+
+            def local_phase():
+                mom = self._moments(j, owned, targets)
+                po.update_scale_given_axis(mom, pr, st, spectral_density=self.spectral_density_prior[j], regions=owned)
+                po.update_axis(pr, po, st, regions=owned)
+                st.update_axis(po, regions=owned)
+                st.update_scale(po, st, regions=owned)
+                po.update_ard(pr, st, self.spectral_density_prior[j], regions=owned)
+                st.update_ard(po, regions=owned)
+                return self._moments(j, owned, targets)                # residuals under the new E[au]
+            mom = self._together(local_phase)
             po.update_bias_given_noise(mom, pr, st, regions=owned, n_samps=self.n_samps[j], reduce=self._sum_over_ranks)
             po.update_noise(mom, y_var, pr, po, st, regions=owned, n_samps=self.n_samps[j], reduce=self._sum_over_ranks)
             st.update_bias(po, regions=owned)
@@ -924,10 +927,12 @@ class ReducedRankMRGP(MultiResolutionGaussianProcess):
             self._targets[j] = targets
             previous = self.shared_prior if j == 0 else self.shared_posterior.snapshot()
 
-            mom = self._moments(j, owned, targets)
-            po.update_scale_given_axis(mom, pr, st, shared_stats=self.shared_stats,
-                                       spectral_density=self.spectral_density_prior[j], regions=owned)
-            evidence = self._sum_over_ranks(po.axis_evidence(st, regions=owned))
+            def local_phase():
+                mom = self._moments(j, owned, targets)
+                po.update_scale_given_axis(mom, pr, st, shared_stats=self.shared_stats,
+                                           spectral_density=self.spectral_density_prior[j], regions=owned)
+                return po.axis_evidence(st, regions=owned)
+            evidence = self._sum_over_ranks(self._together(local_phase))
             self.shared_posterior.update_axis(previous, evidence, self.shared_stats)
             self.shared_stats.update_axis(self.shared_posterior)
             st.update_scale(po, self.shared_stats, regions=owned)
@@ -937,7 +942,7 @@ class ReducedRankMRGP(MultiResolutionGaussianProcess):
             self.shared_posterior.update_ard(previous, self._sum_over_ranks(over_spec), self.n_regions[j], self.shared_stats)
             self.shared_stats.update_ard(self.shared_posterior)
             self.shared_stats.update_omega(previous, self.shared_stats)
-            mom = self._moments(j, owned, targets)
+            mom = self._together(lambda: self._moments(j, owned, targets))
             po.update_bias_given_noise(mom, pr, st, regions=owned, n_samps=self.n_samps[j], reduce=self._sum_over_ranks)
             po.update_noise(mom, y_var, pr, po, st, regions=owned, n_samps=self.n_samps[j], reduce=self._sum_over_ranks)
             st.update_bias(po, regions=owned)
@@ -960,6 +965,20 @@ class ReducedRankMRGP(MultiResolutionGaussianProcess):
         for l in range(self.n_regions[j]):
             self.train_basis_intervals[j][l] = fresh[l].copy()
             self.lambda_[j][l], self.spectral_density_prior[j][l] = self._eigenvalues_and_prior(j, fresh[l])
+
+    def _together(self, local_phase):
+        """Run a rank-local phase (GPU sums + the regions' own updates).  With several ranks an
+        exception on one of them is raised on EVERY rank (``dist.raise_together``) instead of
+        leaving the others blocked in the next collective."""
+        if self.world_size == 1:
+            return local_phase()
+        out, err = None, None
+        try:
+            out = local_phase()
+        except Exception as exc:            # noqa: BLE001 -- re-raised on every rank just below
+            err = exc
+        dist.raise_together(err, self.group, self.device)
+        return out
 
     def _sum_over_ranks(self, host_array):
         if self.world_size == 1:

@@ -71,8 +71,13 @@ class RegressionMethod(object):
 class GP_RBF(RegressionMethod):
     name = 'GP_RBF'
 
-    def __init__(self, lengthscale=1., variance=1., dtype='f64', device=None, optimize=False, max_iters=1000):
+    def __init__(self, lengthscale=1., variance=1., dtype='f64', device=None, optimize=True, max_iters=1000):
+        """``optimize=True`` (default) is the reference's behaviour: its ``_fit`` always calls
+        ``model.optimize()`` (RegressionInput.py:63).  ``optimize=False`` keeps the starting
+        hyper-parameters (GPy's defaults l = 1, variance = 1, noise = 1 % of the label variance):
+        the opt-in fast path, and the definition of the fixed-parameter parity target."""
         super(GP_RBF, self).__init__()
+        self._initial = (float(lengthscale), float(variance))
         self.kernel = RBFKernel(l=lengthscale, sf=variance)
         self.dtype = dev.as_torch_dtype(dtype)
         self.device = device
@@ -130,7 +135,9 @@ class GP_RBF(RegressionMethod):
         device = dev.require_gpu(self.device)
         inputs = np.atleast_2d(np.asarray(inputs, dtype=np.float64))
         labels = np.atleast_2d(np.asarray(labels, dtype=np.float64))
-        # the noise of the plugin is a property of the (z-scored) labels as a whole
+        # every fit starts from the constructor's values (a re-fit does not start from the
+        # previous optimum); the noise of the plugin is a property of the (z-scored) labels as a whole
+        self.kernel = RBFKernel(l=self._initial[0], sf=self._initial[1])
         self.kernel.noise = float(labels.var()) * NOISE_FRACTION
         x = dev.to_device(inputs, self.dtype, device)
         y = dev.to_device(labels, self.dtype, device)

@@ -10,9 +10,10 @@ from .IndexSetGenerator import IndexSetUniform
 from .KernelClass import RBFKernel, MaternKernel, LaplacianEigenpairs
 from .BasisInterval import BasisInterval
 from .RegressionInput import RegressionMethod, GP_RBF
+from .Inputs import space_filling_order
 from .Posteriors import DensePosterior, DenseBlock
 from .MRGP import MultiResolutionGaussianProcess
 from . import _lib, device, dist
 
 __all__ = ["IndexSetUniform", "RBFKernel", "MaternKernel", "LaplacianEigenpairs", "BasisInterval", "RegressionMethod",
-           "GP_RBF", "DensePosterior", "DenseBlock", "MultiResolutionGaussianProcess", "device", "dist"]
+           "GP_RBF", "DensePosterior", "DenseBlock", "MultiResolutionGaussianProcess", "space_filling_order", "device", "dist"]

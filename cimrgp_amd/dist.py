@@ -45,3 +45,26 @@ def allreduce_sum_(tensor, group=None):
     if ws > 1:
         td.all_reduce(tensor, op=td.ReduceOp.SUM, group=group)
     return tensor
+
+
+class RemoteRankError(RuntimeError):
+    """Raised on the ranks that did NOT fail when another rank of the group did."""
+
+
+def raise_together(error, group=None, device=None):
+    """Make a rank-local failure collective.
+
+    ``error``: the exception this rank caught in its local phase, or None.  Every
+    rank of the group calls this at the same point; if any rank holds an error,
+    EVERY rank raises (the failing ones their own exception, the others
+    ``RemoteRankError``) instead of the healthy ranks blocking for ever in the
+    next collective.  Costs one 1-element all-reduce; a no-op for one process."""
+    _, ws = world(group)
+    if ws > 1:
+        flag = torch.tensor([0.0 if error is None else 1.0], dtype=torch.float32,
+                            device=device if device is not None else "cpu")
+        td.all_reduce(flag, op=td.ReduceOp.MAX, group=group)
+        if error is None and float(flag.item()) > 0:
+            raise RemoteRankError("another rank of the process group failed in this phase")
+    if error is not None:
+        raise error

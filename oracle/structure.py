@@ -7,7 +7,7 @@ the reference itself, see ``tests/golden/make_golden.py``).
 import numpy as np
 
 
-def index_bounds_uniform(sample_length, resolution, divider):
+def index_bounds_uniform(sample_length, resolution, divider, first_divider_power=0):
     """Block boundaries of ``IndexSetUniform`` with a uniform divider.
 
     Follows IndexSetGenerator.py:51-65: layer m has ``divider**m`` contiguous
@@ -16,13 +16,17 @@ def index_bounds_uniform(sample_length, resolution, divider):
     holding [start, stop) per region instead of materialised index lists.
     ``resolution == 0`` forces ``divider = 0`` (IndexSetGenerator.py:18-20),
     which still yields one region because ``0**0 == 1``.
+    ``first_divider_power`` p > 0 (not in the reference; root-block policy of
+    BASELINE config 4): layer m has ``divider**(m + p)`` blocks, i.e. the
+    hierarchy starts at a layer whose blocks fit one device.
     """
     sample_length = int(sample_length)
     resolution = int(resolution)
-    divider = 0 if resolution == 0 else int(divider)
+    first_divider_power = int(first_divider_power)
+    divider = 0 if (resolution == 0 and first_divider_power == 0) else int(divider)
     bounds = []
     for m in range(resolution + 1):
-        n_regions = int(np.power(divider, m))
+        n_regions = int(np.power(divider, m + first_divider_power))
         per_region = sample_length // n_regions
         if per_region < 1:
             raise ValueError('*** Chosen resolution is too large! ***')

@@ -92,3 +92,36 @@ def test_single_process_world_is_identity():
     assert dist.world() == (0, 1)
     t = torch.arange(4.0)
     assert dist.allreduce_sum_(t) is t
+
+
+def _failing_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    from cimrgp_amd import dist
+    td.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    # phase 1: nobody fails -> nobody raises
+    dist.raise_together(None)
+    # phase 2: rank 1 fails in its local phase; rank 0 must not be left waiting in the next collective
+    err = np.linalg.LinAlgError("Matrix is not positive definite (leading minor of order 3)") if rank == 1 else None
+    try:
+        dist.raise_together(err)
+        seen = "none"
+    except np.linalg.LinAlgError as exc:
+        seen = "own:" + str(exc)
+    except dist.RemoteRankError as exc:
+        seen = "remote:" + str(exc)
+    # both ranks are still in step: a collective after the failure completes
+    t = torch.ones(1)
+    dist.allreduce_sum_(t)
+    with open(os.path.join(out_dir, "seen%d.txt" % rank), "w") as fh:
+        fh.write("%s|%d" % (seen, int(t.item())))
+    td.destroy_process_group()
+
+
+def test_rank_local_failure_is_raised_on_every_rank(tmp_path):
+    """a failure on one rank (e.g. a non-PD block) must surface on all of them instead of
+    hanging the healthy ranks in the layer's all-reduce."""
+    port = _free_port()
+    mp.spawn(_failing_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    seen = [open(os.path.join(str(tmp_path), "seen%d.txt" % r)).read() for r in range(2)]
+    assert seen[0].startswith("remote:") and seen[0].endswith("|2")
+    assert seen[1].startswith("own:Matrix is not positive definite") and seen[1].endswith("|2")

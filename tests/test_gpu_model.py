@@ -26,7 +26,7 @@ def _relerr(a, b):
 def test_gp_rbf_plugin_matches_oracle(ca, golden_dir):
     g = np.load(os.path.join(golden_dir, "dense_oracle.npz"))
     x, y, xt = g["chain_x"], g["chain_y"], g["chain_xt"]
-    model = ca.GP_RBF()
+    model = ca.GP_RBF(optimize=False)
     assert model.fit([x, y]) is True
     pred = model.predict(xt)
     assert pred.shape == (xt.shape[0], 2)
@@ -255,7 +255,7 @@ def test_log_marginal_likelihood_and_gradient(ca, n, d):
     rng = np.random.default_rng(n)
     x = rng.uniform(-2, 2, size=(n, d))
     y = np.stack([np.sin(2 * x[:, 0]) + x[:, -1], np.cos(x[:, 0] * x[:, -1])], axis=1) + 0.1 * rng.normal(size=(n, 2))
-    model = ca.GP_RBF()
+    model = ca.GP_RBF(optimize=False)
     xd = ca.device.to_device(x, torch.float64, "cuda")
     yd = ca.device.to_device(y, torch.float64, "cuda")
     for ell, sf, noise in [(1.0, 1.0, 0.01), (0.6, 1.7, 0.1)]:
@@ -283,7 +283,7 @@ def test_gp_rbf_optimize_matches_oracle(ca):
     pred = model.predict(xt)
     opred = oracle.gp_rbf_predict(ref, xt)
     assert _relerr(pred, opred) < 1e-4
-    fixed = ca.GP_RBF()
+    fixed = ca.GP_RBF(optimize=False)
     fixed.fit([x, y])
     assert float(np.mean((pred - np.hstack([np.sin(2 * xt), np.cos(3 * xt) + 0.3 * xt])) ** 2)) < \
         float(np.mean((fixed.predict(xt) - np.hstack([np.sin(2 * xt), np.cos(3 * xt) + 0.3 * xt])) ** 2)) * 1.5

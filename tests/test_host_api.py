@@ -95,7 +95,7 @@ def test_rbf_kernel_protocol():
 
 def test_regression_method_preprocessing_matches_reference(golden_dir):
     g = _load(golden_dir, "structure_normalise.npz")
-    plug = ca.GP_RBF()
+    plug = ca.GP_RBF(optimize=False)
     xz, yz = plug._preprocess([g["x1"], g["plug_y"]], True)
     np.testing.assert_array_equal(xz, g["plug_xz"])
     np.testing.assert_array_equal(yz, g["plug_yz"])
@@ -126,3 +126,68 @@ def test_block_assignment_is_deterministic_and_balanced():
     own = assign_blocks([100, 100, 300, 100], 2)
     assert own[2] != own[0] or own[2] != own[1]
     np.testing.assert_array_equal(assign_blocks([5, 7, 7, 3], 3), assign_blocks([5, 7, 7, 3], 3))
+
+
+def test_root_block_policy_index_sets():
+    """BASELINE config 4: the hierarchy starts at a layer whose blocks fit one device
+    (``first_divider_power``); default 0 is the reference's index set, bit for bit."""
+    import oracle
+    ref = ca.IndexSetUniform(1000, 3, 2)
+    same = ca.IndexSetUniform(1000, 3, 2, first_divider_power=0)
+    assert all((a == b).all() for a, b in zip(ref.bounds, same.bounds))
+    idx = ca.IndexSetUniform(262144, 4, 2, first_divider_power=3)
+    assert idx.n_regions_per_layer() == [8, 16, 32, 64, 128]
+    assert [int(b[0, 1] - b[0, 0]) for b in idx.bounds] == [32768, 16384, 8192, 4096, 2048]
+    for got, want in zip(idx.bounds, oracle.index_bounds_uniform(262144, 4, 2, 3)):
+        np.testing.assert_array_equal(got, want)
+    ragged = ca.IndexSetUniform(1003, 1, 2, first_divider_power=2)        # remainder to the last region
+    assert ragged.n_regions_per_layer() == [4, 8] and int(ragged.bounds[1][-1, 1]) == 1003
+    assert ca.IndexSetUniform(100, 0, 2, first_divider_power=2).n_regions_per_layer() == [4]
+    with pytest.raises(ValueError):
+        ca.IndexSetUniform(100, 1, 2, first_divider_power=-1)
+    with pytest.raises(ValueError):
+        ca.IndexSetUniform(100, 3, 2, first_divider_power=5)              # finer than one sample per region
+
+
+def test_space_filling_order():
+    grid = np.array([(i, j) for i in range(16) for j in range(16)], dtype=float)
+    perm = ca.space_filling_order(grid, bits=4)
+    assert sorted(perm.tolist()) == list(range(256))
+    steps = np.abs(np.diff(grid[perm], axis=0)).sum(axis=1)
+    assert (steps == 1).all()                     # a Hilbert curve moves to an edge neighbour every step
+    x1 = np.array([[3.0], [1.0], [2.0]])
+    assert ca.space_filling_order(x1).tolist() == [1, 2, 0]
+    rng = np.random.default_rng(0)
+    x3 = rng.uniform(size=(500, 3))
+    p3 = ca.space_filling_order(x3)
+    assert sorted(p3.tolist()) == list(range(500))
+    # Morton order in 3-D: the first eighth of the curve stays inside one octant
+    first = x3[p3[:40]]
+    assert (np.ptp(first, axis=0) <= 0.55).all()
+
+
+def test_workloads_are_seeded_and_ordered():
+    import workloads
+    x, y = workloads.make_block(256)
+    x2, y2 = workloads.make_block(256)
+    np.testing.assert_array_equal(x, x2)
+    np.testing.assert_array_equal(y, y2)
+    assert (np.diff(x[:, 0]) >= 0).all()
+    xa, ya, xsa = workloads.make_chain_2d(1024, order=ca.space_filling_order)
+    assert xa.shape == (1024, 2) and ya.shape == (1024, 2) and xsa.shape == (256, 2)
+    # train and test points follow ONE curve: test block l lies where train block l lies
+    for tr, te in zip(np.split(xa, 8), np.split(xsa, 8)):
+        assert np.linalg.norm(tr.mean(axis=0) - te.mean(axis=0)) < 0.8
+
+
+def test_hilbert_order_makes_compact_regions():
+    """Contiguous index ranges of Hilbert-sorted 2-D points are compact patches (what an RBF block
+    needs); sorting by one coordinate gives strips as long as the whole domain."""
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1, 1, size=(8192, 2))
+    xs = x[ca.space_filling_order(x)]
+    for k in (8, 128):
+        extent = np.mean([np.max(np.ptp(b, axis=0)) for b in np.split(xs, k)])
+        assert extent < 1.6 * 2.0 / np.sqrt(k)      # longest side close to the ideal square's 2/sqrt(k)
+    strips = np.mean([np.max(np.ptp(b, axis=0)) for b in np.split(x[np.argsort(x[:, 0])], 128)])
+    assert strips > 1.9
