@@ -20,6 +20,8 @@ The structure is the reference's:
 With fixed hyper-parameters one sweep is exact, so ``fit`` runs a single sweep
 whatever ``n_iter`` is (further sweeps would reproduce it bit for bit).
 """
+import weakref
+
 import numpy as np
 import torch
 
@@ -27,7 +29,7 @@ from . import device as dev
 from . import dist
 from .Inputs import Inputs
 from .KernelClass import RBFKernel
-from .Posteriors import DensePosterior
+from .Posteriors import DensePosterior, _Fanout
 
 
 class DenseStats(object):
@@ -35,7 +37,9 @@ class DenseStats(object):
     (Stats.py:7-64): latent function per region, bias and noise per region."""
 
     def __init__(self, model, layer):
-        self._m = model
+        # a proxy, not a reference: model -> stats_obj -> model would be a cycle, and a cycle keeps
+        # tens of GB of Cholesky factors alive until the garbage collector happens to run
+        self._m = weakref.proxy(model)
         self._j = layer
         self.n_regions = model.n_regions[layer]
         self.dy = model.dy
@@ -197,7 +201,9 @@ class MultiResolutionGaussianProcess(object):
     def _fit(self):
         n, q = self._y.shape
         f_bar = torch.zeros_like(self._y)
+        self._layer_events = [torch.cuda.Event(enable_timing=True) for _ in range(self.n_layers + 1)]
         for j in range(self.n_layers):
+            self._layer_events[j].record()
             self._f_bar_layers[j] = f_bar
             # [layer's training-point prediction (N x q) | failure flag]: ONE buffer, one collective
             buf = torch.zeros(n * q + 1, dtype=self.dtype, device=self.device)
@@ -217,8 +223,15 @@ class MultiResolutionGaussianProcess(object):
                 self.posterior_obj[j].check(owned)           # the owner reports the leading minor
                 raise np.linalg.LinAlgError('Matrix is not positive definite (a block of layer %d '
                                             'owned by another rank)' % j)
+        self._layer_events[self.n_layers].record()
         self._f_bar_final = f_bar
         self._fitted = True
+
+    def layer_fit_ms(self):
+        """Device time of each layer of the last sweep (events on the fit's stream)."""
+        torch.cuda.synchronize(self.device)
+        ev = self._layer_events
+        return [float(ev[j].elapsed_time(ev[j + 1])) for j in range(self.n_layers)]
 
     # ------------------------------------------------------------------ predict
     def _prepare_test(self, test_x):
@@ -264,14 +277,21 @@ class MultiResolutionGaussianProcess(object):
             n_layers = index_set.get_n_resolutions() + 1
             for j in range(n_layers):
                 last = (j == n_layers - 1)
-                for l in self._owned(j):
+                owned = self._owned(j)
+                if not owned:
+                    continue
+                # blocks of a layer write disjoint test ranges: in flight together on the stream
+                # pool; layers accumulate into the same ranges and follow one another
+                fan = _Fanout(self.device, len(owned), max(self.n_samps[j][l] for l in owned))
+                for l in owned:
                     a, b = (int(v) for v in index_set.bounds[j][l])
                     blk = self.posterior_obj[j].blocks[l]
-                    if want_var:
-                        extra = float(blk.noise.item()) if (include_noise and last) else 0.0
-                        blk.predict(xs[a:b], mean[a:b], var[a:b], extra_var=extra)
-                    else:
-                        blk.predict(xs[a:b], mean[a:b], None)
+                    with torch.cuda.stream(fan.stream()):
+                        if want_var:
+                            blk.predict(xs[a:b], mean[a:b], var[a:b], add_noise=(include_noise and last))
+                        else:
+                            blk.predict(xs[a:b], mean[a:b], None)
+                fan.join()
         if self.world_size > 1:
             fused[:self.dy] = mean.t()
             dist.allreduce_sum_(fused, self.group)

@@ -8,6 +8,8 @@ projected targets y~ (Posteriors.py:35-78), this class builds the RBF Gram
 matrix of the region, factors it and solves for the weights -- D1, D2, D3 of
 SURVEY.md 8a' -- through the hand-written HIP kernels.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -15,6 +17,60 @@ from . import device as dev
 
 NOISE_FRACTION = 0.01    # RegressionInput.py:62: labels.var() * 0.01
 NOISE_FLOOR = 1e-8       # x sf: keeps a constant-target block positive definite
+
+# ---- independent blocks of one layer run concurrently (the reference's independent-over-l loop,
+# Posteriors.py:35-59): a small pool of streams per device; blocks are dealt round-robin.
+_POOLS = {}
+
+
+def block_streams(device, n_blocks, n_max):
+    """How many blocks of a layer are in flight at once, and on which streams.  Small blocks are
+    latency-bound (one queue each, ~10 % of the machine) and overlap almost perfectly; large ones
+    already fill the machine with their trailing updates.  ``CIMRGP_BLOCK_STREAMS`` overrides."""
+    env = os.environ.get("CIMRGP_BLOCK_STREAMS")
+    if env is not None:
+        want = int(env)
+    elif n_max <= 5120:
+        want = 8
+    elif n_max <= 12288:
+        want = 3
+    elif n_max <= 20480:
+        want = 2
+    else:
+        want = 1
+    want = max(1, min(want, n_blocks))
+    if want == 1:
+        return []
+    key = (torch.device(device).index, )
+    pool = _POOLS.setdefault(key, [])
+    while len(pool) < want:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:want]
+
+
+class _Fanout(object):
+    """Deal work items to pool streams: every stream starts after what is queued on the caller's
+    stream, the caller's stream continues after all of them (events only, no host wait)."""
+
+    def __init__(self, device, n_items, n_max):
+        self.main = torch.cuda.current_stream(device)
+        self.pool = block_streams(device, n_items, n_max)
+        self.i = 0
+        if self.pool:
+            start = self.main.record_event()
+            for s in self.pool:
+                s.wait_event(start)
+
+    def stream(self):
+        if not self.pool:
+            return self.main
+        s = self.pool[self.i % len(self.pool)]
+        self.i += 1
+        return s
+
+    def join(self):
+        for s in self.pool:
+            self.main.wait_stream(s)
 
 
 class DenseBlock(object):
@@ -66,9 +122,16 @@ class DenseBlock(object):
             self.z = None
         self.r = None
 
-    def predict(self, xs, mean_out, var_out=None, extra_var=0.0, chunk=16384):
+    def hand_over_to(self, stream):
+        """The block was fitted on a pool stream; its tensors are used on ``stream`` from now on."""
+        for t in (self.lbuf, self.ws, self.info, self.alpha, self.z, self.bias, self.noise):
+            if t is not None:
+                t.record_stream(stream)
+
+    def predict(self, xs, mean_out, var_out=None, extra_var=0.0, chunk=16384, add_noise=False):
         """Accumulate this block's predictive mean (and latent variance) at ``xs``
-        into ``mean_out`` (ns x q) / ``var_out`` (ns,)."""
+        into ``mean_out`` (ns x q) / ``var_out`` (ns,).  ``add_noise``: add the block's noise
+        variance, read from the device (no host round trip)."""
         k = self.kernel
         if var_out is None:
             dev.predict_mean(self.x, self.alpha, xs, k.l, k.sf, self.bias, out=mean_out, accumulate=True)
@@ -81,7 +144,8 @@ class DenseBlock(object):
             w = dev.rbf_cross(xs[s0:s1], self.x, k.l, k.sf)
             dev.trsm_rows(self.lbuf, self.n, self.ws, w, s1 - s0)
             dev.predict_from_w(w, s1 - s0, self.n, self.z, k.sf, extra_var, self.bias,
-                               mean_out[s0:s1], var_out[s0:s1], accumulate=True)
+                               mean_out[s0:s1], var_out[s0:s1], accumulate=True,
+                               extra_var_dev=self.noise if add_noise else None)
 
     def log_marginal_likelihood(self, r_dot_alpha):
         """-1/2 r^T alpha - sum log L_ii - n/2 log 2pi, per output column summed."""
@@ -116,10 +180,18 @@ class DensePosterior(object):
                 shared_bias = stats[:self.dy]
             if not self.noise_region_specific and self.kernel.noise is None:
                 shared_noise = dev.noise_from_stats(stats, self.dy, NOISE_FRACTION, NOISE_FLOOR * self.kernel.sf)
+        regions = list(regions)
+        if not regions:
+            return
+        fan = _Fanout(y_mean[regions[0]].device, len(regions), max(int(x[l].shape[0]) for l in regions))
         for l in regions:
-            blk = DenseBlock(x[l], self.kernel)
-            blk.fit(y_mean[l], f_bar[l], train_out[l], shared_bias, shared_noise, keep_factor=keep_factors)
+            with torch.cuda.stream(fan.stream()):
+                blk = DenseBlock(x[l], self.kernel)
+                blk.fit(y_mean[l], f_bar[l], train_out[l], shared_bias, shared_noise, keep_factor=keep_factors)
+                if fan.pool:
+                    blk.hand_over_to(fan.main)
             self.blocks[l] = blk
+        fan.join()
 
     @staticmethod
     def _whole_layer(views):

@@ -25,6 +25,8 @@ regions of ``device.BlockMoments`` reduced on the GPU.  Supported: region-specif
 noise / bias, fixed and adaptive basis intervals (``BasisInterval``), SNR-initialised noise,
 input warping, the lower bound of ``fit(n_iter, tol)``; priors are the non-informative ones.
 """
+import weakref
+
 import numpy as np
 import torch
 from scipy.optimize import fsolve
@@ -570,7 +572,7 @@ class _LayerStatsView(object):
     reference's per-region list form (Stats.py:56-62)."""
 
     def __init__(self, model, layer):
-        self._m, self._j = model, layer
+        self._m, self._j = weakref.proxy(model), layer     # no model <-> view cycle
 
     def latent(self):
         f, v = self._m._latent[self._j]

@@ -10,7 +10,7 @@ F32, F64 = 0, 1
 NB = 256
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcimrgp.so")
+LIB_PATH = os.environ.get("CIMRGP_LIB_PATH", os.path.join(_HERE, "libcimrgp.so"))   # override: A/B builds of the library
 
 _vp, _i64, _i32, _dbl, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_size_t
 
@@ -28,7 +28,7 @@ SIGNATURES = {
     "cimrgp_potrs": (_i32, [_i32, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _vp]),
     "cimrgp_trsm_rows": (_i32, [_i32, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp]),
     "cimrgp_predict_mean": (_i32, [_i32, _vp, _i64, _i32, _vp, _i32, _vp, _i64, _dbl, _dbl, _vp, _vp, _i32, _vp]),
-    "cimrgp_predict_from_w": (_i32, [_i32, _vp, _i64, _i64, _i64, _vp, _i32, _dbl, _dbl, _vp, _vp, _vp, _i32, _vp]),
+    "cimrgp_predict_from_w": (_i32, [_i32, _vp, _i64, _i64, _i64, _vp, _i32, _dbl, _dbl, _vp, _vp, _vp, _vp, _i32, _vp]),
     "cimrgp_block_stats": (_i32, [_i32, _vp, _vp, _i64, _i32, _vp, _vp]),
     "cimrgp_residual": (_i32, [_i32, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "cimrgp_train_mean": (_i32, [_i32, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp]),

@@ -172,8 +172,8 @@ int cimrgp_predict_mean(int dtype, const void* x_dev, int64_t n, int d, const vo
 }
 
 int cimrgp_predict_from_w(int dtype, const void* w_dev, int64_t ns, int64_t n, int64_t ldw, const void* z_dev, int q,
-                          double sf2, double extra_var, const void* bias_dev, void* mean_dev, void* var_dev,
-                          int accumulate, void* stream)
+                          double sf2, double extra_var, const void* extra_var_dev, const void* bias_dev, void* mean_dev,
+                          void* var_dev, int accumulate, void* stream)
 {
     const char* fn = "cimrgp_predict_from_w";
     CIMRGP_REQUIRE(w_dev, fn, "null pointer");
@@ -181,10 +181,11 @@ int cimrgp_predict_from_w(int dtype, const void* w_dev, int64_t ns, int64_t n, i
     CIMRGP_REQUIRE(mean_dev == nullptr || z_dev != nullptr, fn, "mean requested without z");
     DISPATCH(dtype, fn,
              predict_from_w_run<float>((const float*)w_dev, ns, n, ldw, (const float*)z_dev, q, sf2, extra_var,
-                                       (const float*)bias_dev, (float*)mean_dev, (float*)var_dev, accumulate, S(stream)),
+                                       (const float*)extra_var_dev, (const float*)bias_dev, (float*)mean_dev,
+                                       (float*)var_dev, accumulate, S(stream)),
              predict_from_w_run<double>((const double*)w_dev, ns, n, ldw, (const double*)z_dev, q, sf2, extra_var,
-                                        (const double*)bias_dev, (double*)mean_dev, (double*)var_dev, accumulate,
-                                        S(stream)));
+                                        (const double*)extra_var_dev, (const double*)bias_dev, (double*)mean_dev,
+                                        (double*)var_dev, accumulate, S(stream)));
 }
 
 int cimrgp_block_stats(int dtype, const void* y_dev, const void* fbar_dev, int64_t n, int q, void* stats_dev, void* stream)

@@ -121,7 +121,8 @@ template <typename T> int predict_mean_run(const T* x, int64_t n, int d, const T
 template <typename T> int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* z_out, T* scratch,
                                     bool backward_only, hipStream_t st);
 template <typename T> int predict_from_w_run(const T* w, int64_t ns, int64_t n, int64_t ldw, const T* z, int q, double sf2,
-                                             double extra, const T* bias, T* mean, T* var, int accumulate, hipStream_t st);
+                                             double extra, const T* extra_dev, const T* bias, T* mean, T* var, int accumulate,
+                                             hipStream_t st);
 // misc.hip
 template <typename T> int misc_block_stats(const T* y, const T* fbar, int64_t n, int q, T* stats, hipStream_t st);
 template <typename T> int misc_residual(const T* y, const T* fbar, const T* bias, int64_t n, int q, T* r, hipStream_t st);

@@ -249,6 +249,10 @@ int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t 
     // each; measured sweep of the switch point inside the factorisation at N = 8192:
     // 256/512/768/1024/1536 tiles -> 91.3/93.5/94.2/91.9/90.6 posteriors/s)
     const int64_t t128 = ((m + 127) / 128) * ((n + 127) / 128) / (lower ? 2 : 1);
+    // tiny updates on the factorisation's critical path (the 256 x 256 diagonal block): 32-tiles, so
+    // that the K loop of a tile is 1/4 as long and ~36 compute units share it instead of 10
+    const int64_t t64 = ((m + 63) / 64) * ((n + 63) / 64) / (lower ? 2 : 1);
+    if (t64 < 32) return gemm_launch<T, 1>(c, ldc, a, lda, b, ldb, m, n, k, lower, st);
     if (t128 < 768) return gemm_launch<T, 2>(c, ldc, a, lda, b, ldb, m, n, k, lower, st);
     return gemm_launch<T, 4>(c, ldc, a, lda, b, ldb, m, n, k, lower, st);
 }

@@ -630,11 +630,12 @@ void k_invT_step(T* __restrict__ invT, const T* __restrict__ L, int64_t ld, int 
 // TF/s at M = 15360, 55.5 / 62.1 / 64.3 / 65.3 TF/s at M = 32256.  Inside the factorisation
 // (whole potrf, groups capped at 1 / 2 / 3 / 4): N = 32768: 217.8 / 203.9 / 201.3 / 200.9 ms,
 // N = 65536: 1650 / 1512 / 1505 / 1505 ms -- pairs bring most of it.  The group is also kept
-// small enough for the operand panel (far x K x 8 bytes) to fit the 256 MB Infinity Cache.
+// small enough for the operand panel (far x K x 8 bytes) to fit the 256 MB Infinity Cache, which
+// caps it at 3 (a group of 4 would need far > 32768 and far <= 32768 at once).
 static inline int group_size(int64_t far, int64_t pair_above)
 {
     if (far <= pair_above) return 1;
-    const int by_benefit = (far > 32768) ? 4 : (far > 16384 ? 3 : 2);
+    const int by_benefit = (far > 16384) ? 3 : 2;
     const int64_t by_cache = ((int64_t)1 << 17) / far;       // 2^28 bytes / (8 bytes x far rows x 256 columns)
     const int g = (by_cache < by_benefit) ? (int)by_cache : by_benefit;
     return g < 1 ? 1 : g;
@@ -743,55 +744,88 @@ static int panel_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info,
 // pool are created once per device and reused.
 // ---------------------------------------------------------------------------
 namespace {
+constexpr int MAX_CTX = 8;               // look-ahead contexts per device: one per concurrently factoring caller stream
+constexpr int64_t SINGLE_QUEUE_MAX = 5120;   // n at or below this: one queue, no look-ahead (see potrf_run)
+
 struct LookAhead {
     hipStream_t side = nullptr;        // panel chain (high priority, all compute units)
     hipStream_t bulk = nullptr;        // trailing updates: every compute unit but the reserved ones
     hipStream_t rows = nullptr;        // carried rows: lags behind the factorisation; same mask as bulk
     std::vector<hipEvent_t> ev;
-    int device = -1;
-    std::mutex enqueue;                // one factorisation at a time enqueues on this device's side queues
+    hipStream_t owner = nullptr;       // the caller stream this context was created for
+    std::mutex enqueue;                // one factorisation at a time enqueues on this context's queues
 };
-LookAhead g_la[16];
+std::mutex g_reg_mutex;                // guards g_ctx and context creation
+std::vector<LookAhead*> g_ctx[16];     // per device; contexts live as long as the process
 
-LookAhead* lookahead_ctx(size_t nevents)
+// Streams of one context.  All three or none: a context without its rows queue would have to
+// order the carried rows on the caller's stream, which the schedule below does not do.
+LookAhead* make_ctx(int dev)
+{
+    LookAhead* la = new LookAhead;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    bool ok = hipStreamCreateWithPriority(&la->side, hipStreamNonBlocking, hi) == hipSuccess;
+    // Optional (CIMRGP_RESERVE_CUS = R, default 0 = off): reserve R compute units of every XCD
+    // for the latency-bound chain by running the MFMA-bound update kernels on queues whose CU
+    // mask excludes them.  Mask bit b is CU b / 8 of XCD b % 8 (measured: a mask that thins out
+    // ONE XCD slows a kernel by that XCD's loss, because workgroups are dealt round-robin to
+    // the XCDs).  Measured twice and rejected as a default: in round 1 the end-to-end time did
+    // not move (N = 8192: 7.77 vs 7.79 ms); in round 2, with every wide kernel moved off the chain
+    // queue, masked queues slowed the WHOLE step (94 -> 54 posteriors/s): hipExtStreamCreateWithCUMask
+    // makes blocking streams, which synchronise implicitly with the caller's default stream.
+    const char* env = getenv("CIMRGP_RESERVE_CUS");
+    const int reserve = env ? atoi(env) : 0;
+    hipDeviceProp_t prop;
+    if (ok && reserve > 0 && reserve < 8 && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount == 256) {
+        uint32_t mask[8];
+        for (int wd = 0; wd < 8; ++wd) mask[wd] = 0xffffffffu;
+        for (int bit = 0; bit < 8 * reserve; ++bit) mask[bit >> 5] &= ~(1u << (bit & 31));
+        if (hipExtStreamCreateWithCUMask(&la->bulk, 8, mask) != hipSuccess) la->bulk = nullptr;
+        if (hipExtStreamCreateWithCUMask(&la->rows, 8, mask) != hipSuccess) la->rows = nullptr;
+    }
+    if (ok && la->rows == nullptr) ok = hipStreamCreateWithPriority(&la->rows, hipStreamNonBlocking, lo) == hipSuccess;
+    if (!ok) {
+        if (la->side) (void)hipStreamDestroy(la->side);
+        if (la->bulk) (void)hipStreamDestroy(la->bulk);
+        if (la->rows) (void)hipStreamDestroy(la->rows);
+        delete la;
+        return nullptr;
+    }
+    return la;
+}
+
+// The context serving caller stream `st` on the current device (created on first use under the
+// registry lock; beyond MAX_CTX contexts callers share one by stream hash, which only serialises
+// them on its queues).  Independent blocks of a layer are factored on different caller streams
+// and so get different contexts: their panel chains run side by side.
+LookAhead* acquire_ctx(hipStream_t st)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    LookAhead& la = g_la[dev];
-    if (la.side == nullptr) {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (hipStreamCreateWithPriority(&la.side, hipStreamNonBlocking, hi) != hipSuccess) { la.side = nullptr; return nullptr; }
-        // Optional (CIMRGP_RESERVE_CUS = R, default 0 = off): reserve R compute units of every XCD
-        // for the latency-bound chain by running the MFMA-bound update kernels on queues whose CU
-        // mask excludes them.  Mask bit b is CU b / 8 of XCD b % 8 (measured: a mask that thins out
-        // ONE XCD slows a kernel by that XCD's loss, because workgroups are dealt round-robin to
-        // the XCDs), so the low 8 R bits take R CUs from each of the 8 XCDs and cost the update
-        // R / 32 of its rate.  Measured effect: what stretches a chain kernel beside a running
-        // update is not its execution but the WAIT FOR A SLOT -- two update workgroups fill a CU's
-        // registers and LDS -- (the single-workgroup diagonal kernel: 56..220 us between its events,
-        // 20 us inside; with R = 1: 29 us).  The chain's wide links (panel solve, head update)
-        // need the whole machine and wait just the same, so the end-to-end time does not move
-        // (N = 8192: 7.77 vs 7.79 ms; with carried rows 10.7 vs 9.6 ms): off by default.
-        const char* env = getenv("CIMRGP_RESERVE_CUS");
-        const int reserve = env ? atoi(env) : 0;
-        hipDeviceProp_t prop;
-        if (reserve > 0 && reserve < 8 && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount == 256) {
-            uint32_t mask[8];
-            for (int wd = 0; wd < 8; ++wd) mask[wd] = 0xffffffffu;
-            for (int bit = 0; bit < 8 * reserve; ++bit) mask[bit >> 5] &= ~(1u << (bit & 31));
-            if (hipExtStreamCreateWithCUMask(&la.bulk, 8, mask) != hipSuccess) la.bulk = nullptr;
-            if (hipExtStreamCreateWithCUMask(&la.rows, 8, mask) != hipSuccess) la.rows = nullptr;
-        }
-        if (la.rows == nullptr && hipStreamCreateWithPriority(&la.rows, hipStreamNonBlocking, lo) != hipSuccess) la.rows = nullptr;
-        la.device = dev;
+    std::lock_guard<std::mutex> guard(g_reg_mutex);
+    std::vector<LookAhead*>& list = g_ctx[dev];
+    for (LookAhead* la : list)
+        if (la->owner == st) return la;
+    if ((int)list.size() < MAX_CTX) {
+        LookAhead* la = make_ctx(dev);
+        if (la == nullptr) return list.empty() ? nullptr : list[0];
+        la->owner = st;
+        list.push_back(la);
+        return la;
     }
-    while (la.ev.size() < nevents) {
+    return list[(reinterpret_cast<uintptr_t>(st) >> 6) % MAX_CTX];
+}
+
+// Event pool of a context; call with la->enqueue held.
+bool grow_events(LookAhead* la, size_t nevents)
+{
+    while (la->ev.size() < nevents) {
         hipEvent_t e;
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-        la.ev.push_back(e);
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+        la->ev.push_back(e);
     }
-    return &la;
+    return true;
 }
 
 template <typename T>
@@ -847,15 +881,19 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     const bool rows = (b != nullptr && m > 0);
     CIMRGP_HIP_TRY(hipMemsetAsync(info, 0, sizeof(int32_t), st), "hipMemsetAsync(info)");
     const int64_t npanels = (n + CIMRGP_NB - 1) / CIMRGP_NB;
-    LookAhead* la = (npanels > 2) ? lookahead_ctx((size_t)(7 * npanels + 8)) : nullptr;
+    // Small matrices: one queue.  Measured in round 1 (whole potrf, one queue vs look-ahead): n = 2048:
+    // 1.23 vs 1.37 ms, 4096: 2.80 vs 3.04 -- and independent blocks of a layer run concurrently on
+    // their callers' streams, which fills the machine better than look-ahead inside each of them.
+    LookAhead* la = (n > SINGLE_QUEUE_MAX && npanels > 2) ? acquire_ctx(st) : nullptr;
     if (la == nullptr) {
         int rc0 = panel_sweep<T, true>(k, n, ld, ws, info, b, m, ldb, st);
         return rc0 ? rc0 : build_invT<T>(k, n, ld, ws, st);
     }
 
-    // Host threads driving the same device share the side queues and the event pool: serialise the
-    // ENQUEUE (microseconds); the queued work of two factorisations may still overlap on the GPU.
+    // Host threads whose streams share a context serialise their ENQUEUE (microseconds); distinct
+    // caller streams have distinct contexts and enqueue concurrently.
     std::lock_guard<std::mutex> guard(la->enqueue);
+    if (!grow_events(la, (size_t)(7 * npanels + 8))) return fail("cimrgp_potrf", "hipEventCreate failed");
     hipStream_t sp = la->side;
     hipStream_t sb = la->bulk ? la->bulk : st;         // bulk trailing updates
     size_t ne = 0;
@@ -889,10 +927,10 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     // compute units the latency-bound panel chain leaves idle.
     auto rows_after_panel = [&](int64_t k0, int64_t k1, hipEvent_t ev_final) -> int {
         if (!rows) return 0;
-        hipStream_t sq = la->rows ? la->rows : st;
-        const bool defer = (sq != st) && (n - k1 > ROWS_START_BELOW) && (k1 < n);
+        hipStream_t sq = la->rows;                     // always present (make_ctx: all queues or no context)
+        const bool defer = (n - k1 > ROWS_START_BELOW) && (k1 < n);
         if (defer) return 0;
-        if (sq != st) CIMRGP_HIP_TRY(hipStreamWaitEvent(sq, ev_final, 0), "hipStreamWaitEvent");
+        CIMRGP_HIP_TRY(hipStreamWaitEvent(sq, ev_final, 0), "hipStreamWaitEvent");
         // (pairing the rows' updates below that size was measured neutral-to-worse at N = 8192)
         for (int64_t r0 = rows_next; r0 <= k0; r0 += CIMRGP_NB) {
             int rcr = rows_panel_step<T>(b, ldb, m, k, ld, n, ws, r0, rows_grp, FAR_PAIR_ABOVE, sq, "cimrgp_potrf_rows");

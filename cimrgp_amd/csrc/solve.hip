@@ -232,8 +232,8 @@ void k_bwd_panel(const T* __restrict__ L, int64_t ld, int n, const T* __restrict
 template <typename T, int Q>
 __global__ __launch_bounds__(256)
 void k_predict_from_w(const T* __restrict__ W, int ns, int n, int64_t ldw, const T* __restrict__ z, int q,
-                      T sf2_plus, const T* __restrict__ bias, T* __restrict__ mean, T* __restrict__ var,
-                      int accumulate)
+                      T sf2_plus, const T* __restrict__ extra_dev, const T* __restrict__ bias, T* __restrict__ mean,
+                      T* __restrict__ var, int accumulate)
 {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -261,7 +261,7 @@ void k_predict_from_w(const T* __restrict__ W, int ns, int n, int64_t ldw, const
             sm[c] += __shfl_xor(sm[c], off, 64);
     }
     if (lane == 0) {
-        if (var) { const T v = sf2_plus - ss; var[row] = accumulate ? var[row] + v : v; }
+        if (var) { const T v = sf2_plus + (extra_dev ? extra_dev[0] : (T)0) - ss; var[row] = accumulate ? var[row] + v : v; }
         if (want_mean) {
 #pragma unroll
             for (int c = 0; c < Q; ++c) {
@@ -335,14 +335,14 @@ int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* 
 
 template <typename T>
 int predict_from_w_run(const T* w, int64_t ns, int64_t n, int64_t ldw, const T* z, int q, double sf2,
-                       double extra, const T* bias, T* mean, T* var, int accumulate, hipStream_t st)
+                       double extra, const T* extra_dev, const T* bias, T* mean, T* var, int accumulate, hipStream_t st)
 {
     const char* fn = "cimrgp_predict_from_w";
     if (ns <= 0) return 0;
     CIMRGP_REQUIRE(q >= 0 && q <= MAXQ, fn, "number of outputs must be <= 8");
     CIMRGP_REQUIRE(ns < (1ll << 31) && n < (1ll << 31), fn, "too many points");
     CIMRGP_Q_SWITCH(q > 0 ? q : 1, hipLaunchKernelGGL((k_predict_from_w<T, QQ>), dim3((unsigned)((ns + 3) / 4)), dim3(256), 0, st,
-                                                      w, (int)ns, (int)n, ldw, z, q, (T)(sf2 + extra), bias, mean, var, accumulate));
+                                                      w, (int)ns, (int)n, ldw, z, q, (T)(sf2 + extra), extra_dev, bias, mean, var, accumulate));
     CIMRGP_LAUNCH_CHECK(fn);
     return 0;
 }
@@ -350,8 +350,8 @@ int predict_from_w_run(const T* w, int64_t ns, int64_t n, int64_t ldw, const T* 
 template int potrs_run<double>(const double*, int64_t, int64_t, const double*, double*, int, double*, double*, bool, hipStream_t);
 template int potrs_run<float>(const float*, int64_t, int64_t, const float*, float*, int, float*, float*, bool, hipStream_t);
 template int predict_from_w_run<double>(const double*, int64_t, int64_t, int64_t, const double*, int, double, double,
-                                        const double*, double*, double*, int, hipStream_t);
+                                        const double*, const double*, double*, double*, int, hipStream_t);
 template int predict_from_w_run<float>(const float*, int64_t, int64_t, int64_t, const float*, int, double, double,
-                                       const float*, float*, float*, int, hipStream_t);
+                                       const float*, const float*, float*, float*, int, hipStream_t);
 
 }  // namespace cimrgp

@@ -172,12 +172,14 @@ def predict_mean(x, alpha, xs, ell, sf2, bias=None, out=None, accumulate=False):
     return out
 
 
-def predict_from_w(wbuf, ns, n, z, sf2, extra_var=0.0, bias=None, mean_out=None, var_out=None, accumulate=False):
+def predict_from_w(wbuf, ns, n, z, sf2, extra_var=0.0, bias=None, mean_out=None, var_out=None, accumulate=False,
+                   extra_var_dev=None):
+    """``extra_var``: host number; ``extra_var_dev``: device scalar (e.g. a block's noise) -- both are added."""
     lib = _lib.load()
     q = 0 if z is None else z.shape[1]
     _lib.check(lib.cimrgp_predict_from_w(_DT[wbuf.dtype], _p(wbuf), int(ns), int(n), wbuf.stride(0), _p(z), q,
-                                         float(sf2), float(extra_var), _p(bias), _p(mean_out), _p(var_out),
-                                         int(bool(accumulate)), _stream()), "cimrgp_predict_from_w")
+                                         float(sf2), float(extra_var), _p(extra_var_dev), _p(bias), _p(mean_out),
+                                         _p(var_out), int(bool(accumulate)), _stream()), "cimrgp_predict_from_w")
 
 
 def block_stats(y, fbar, stats_out=None):

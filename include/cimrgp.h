@@ -123,12 +123,16 @@ int cimrgp_predict_mean(int dtype, const void* x_dev, int64_t n, int d,
                         void* mean_dev, int accumulate, void* stream);
 
 /* ---- D5 tail: from W = K(X*,X) L^-T  (ns x n, after cimrgp_trsm_rows) ------
- *   var[i]     (+)= sf2 + extra_var - sum_j W[i][j]^2
+ *   var[i]     (+)= sf2 + extra_var + extra_var_dev[0] - sum_j W[i][j]^2
  *   mean[i][c] (+)= bias[c] + sum_j W[i][j] z[j][c]        (if mean_dev)
- * z_dev (n x q) = L^-1 R from cimrgp_potrs.  mean_dev/var_dev may be NULL. */
+ * z_dev (n x q) = L^-1 R from cimrgp_potrs.  mean_dev/var_dev may be NULL.
+ * extra_var_dev (may be NULL): one device scalar of dtype, e.g. a block's noise
+ * variance as left on the device by cimrgp_noise_from_stats -- the y_var term of
+ * MRGP.py:907-932 without a host round trip. */
 int cimrgp_predict_from_w(int dtype, const void* w_dev, int64_t ns, int64_t n,
                           int64_t ldw, const void* z_dev, int q,
-                          double sf2, double extra_var, const void* bias_dev,
+                          double sf2, double extra_var,
+                          const void* extra_var_dev, const void* bias_dev,
                           void* mean_dev, void* var_dev, int accumulate,
                           void* stream);
 

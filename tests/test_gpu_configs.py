@@ -208,14 +208,15 @@ def _rank_worker(rank, world, port, out_dir, case):
         out = dict(mean=mean, var=var, f_bar=model._f_bar_final.cpu().numpy(),
                    owned=np.array([len(model._owned(j)) for j in range(res + 1)]))
     elif case == "nonpd":
-        # layer 1 has two regions; rank 1 owns the second.  A negative "noise" makes every block of
-        # that layer indefinite (K - 0.5 I), deterministically.  BOTH ranks must raise, neither may hang.
+        # layer 1 has two regions, one per rank.  Rank 1 gives its block a negative "noise" (K - 0.5 I
+        # is indefinite, deterministically); rank 0's block is healthy.  BOTH ranks must raise -- the
+        # owner with LAPACK's leading-minor message, the other one instead of hanging in the all-reduce.
         n = 256
         x = np.linspace(0.0, 1.0, n)[:, None]
         y = np.hstack([np.sin(4 * x), np.cos(3 * x)])
         model = ca.MultiResolutionGaussianProcess([x, y], index_set_obj=ca.IndexSetUniform(n, 1, 2),
                                                   spectral_density_obj=[ca.RBFKernel(l=1.0, sf=1.0, noise=0.05),
-                                                                        ca.RBFKernel(l=0.5, sf=1.0, noise=-0.5)])
+                                                                        ca.RBFKernel(l=0.5, sf=1.0, noise=(-0.5 if rank == 1 else 0.05))])
         owner = model.owner[1].tolist()
         try:
             model.fit()

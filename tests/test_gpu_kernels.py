@@ -102,6 +102,42 @@ def test_potrf_f64_matches_lapack(dev, n):
         assert np.all(np.tril(inv_t[p], -1) == 0)
 
 
+@pytest.mark.parametrize("n,m", [(5184, 0), (5377, 70), (6000, 33), (5632, 0)])
+def test_potrf_lookahead_path_matches_lapack(dev, n, m):
+    """Sizes just above the one-queue limit (5120): the three-queue look-ahead schedule with a
+    ragged last panel (5184 = 20 panels + 64, 5377 = 21 + 1, 6000 = 23 + 112 columns), with and
+    without carried rows, against LAPACK on the whole matrix."""
+    rng = np.random.default_rng(n)
+    x = np.sort(rng.uniform(-2.0, 2.0, size=(n, 1)), axis=0)
+    ell, sf2, noise = 0.05, 1.0, 0.01
+    xd = dev.to_device(x, torch.float64, "cuda")
+    kbuf = dev.rbf_gram(xd, ell, sf2, noise, lower_only=True)
+    lref, iref = oracle.potrf_lower(oracle.rbf_gram(x, None, ell, sf2, noise))
+    assert iref == 0
+    if m:
+        bmat = rng.normal(size=(m, n))
+        bbuf = dev.alloc_matrix(m, n, torch.float64, "cuda")
+        bbuf[:m, :n] = torch.from_numpy(bmat).cuda()
+        ws, info = dev.potrf_rows(kbuf, n, bbuf, m)
+    else:
+        ws, info = dev.potrf(kbuf, n)
+    assert int(info.item()) == 0
+    lmat = torch.tril(kbuf[:n, :n]).cpu().numpy()
+    assert np.max(np.abs(lmat - lref)) / np.max(np.abs(lref)) < 1e-10
+    if m:
+        import scipy.linalg as sla
+        want = sla.solve_triangular(lref, bmat.T, lower=True).T          # B L^-T
+        got = bbuf[:m, :n].cpu().numpy()
+        assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 1e-9
+    # the stored 256 x 256 inverses serve the skinny solves afterwards
+    r = rng.normal(size=(n, 2))
+    rd = dev.to_device(r, torch.float64, "cuda")
+    dev.potrs(kbuf, n, ws, rd)
+    import scipy.linalg as sla
+    want = sla.cho_solve((lref, True), r)
+    assert np.max(np.abs(rd.cpu().numpy() - want)) / np.max(np.abs(want)) < 1e-8
+
+
 @pytest.mark.parametrize("n", [64, 257, 1025])
 def test_potrf_f32(dev, n):
     x, _ = _data(n, 2, seed=n)

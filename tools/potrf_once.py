@@ -1,5 +1,9 @@
 """One warmed-up potrf (optionally with carried rows) at size n for kernel-trace timelines:
    rocprofv3 --kernel-trace -d gpurun_out/trace -- python3 tools/potrf_once.py [n] [reps] [rows]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sys
 
 import numpy as np

@@ -1,4 +1,8 @@
 """Time cimrgp_potrf alone at size n (f64): python tools/potrf_time.py n [reps]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sys
 import json
 import numpy as np

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Turn a rocprofv3 --kernel-trace CSV into a timeline of the LAST factorisation in it:
+   rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace -- python3 tools/potrf_once.py 8192 3
+   python3 tools/timeline.py gpurun_out/trace > profiles/rNN_timeline_n8192.txt
+columns: start_us end_us duration_us queue kernel [grid workgroups]"""
+import csv
+import glob
+import os
+import re
+import sys
+
+
+def short(name):
+    name = re.sub(r"^void\s+", "", name)
+    m = re.search(r"k_gemm_nt_sub<(\w+), (true|false), (\d)>", name)
+    if m:
+        return "k_gemm_nt_sub<%s,%s-tile>" % ("lower" if m.group(2) == "true" else "rect", 32 * int(m.group(3)))
+    name = re.sub(r"cimrgp::\(anonymous namespace\)::", "", name)
+    name = re.sub(r"<.*", "", name)
+    return name.split("(")[0][:48]
+
+
+def main():
+    root = sys.argv[1]
+    files = glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True)
+    if not files:
+        raise SystemExit("no *kernel_trace.csv under " + root)
+    rows = []
+    with open(sorted(files)[-1]) as fh:
+        for r in csv.DictReader(fh):
+            rows.append(dict(name=r["Kernel_Name"], q=r.get("Queue_Id", "?"), s=int(r["Start_Timestamp"]),
+                             e=int(r["End_Timestamp"]),
+                             wg=(int(r.get("Grid_Size_X", r.get("Grid_Size", "0")) or 0) // max(1, int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", "1")) or 1)))))
+    rows.sort(key=lambda r: r["s"])
+    # the last factorisation = from the last Gram build on
+    start = 0
+    for i, r in enumerate(rows):
+        if "k_rbf_gram" in r["name"]:
+            start = i
+    rows = rows[start:]
+    t0 = rows[0]["s"]
+    queues = {}
+    print("# columns: start_us end_us duration_us queue kernel workgroups")
+    print("# total span: %.1f us" % ((max(r["e"] for r in rows) - t0) / 1e3))
+    diag = [r["s"] for r in rows if "k_diag64" in r["name"] or "k_diag256" in r["name"]]
+    per_panel = diag[::4] if any("k_diag64" in r["name"] for r in rows) else diag
+    print("# period between consecutive panels (first diagonal kernel to first diagonal kernel, us): " +
+          " ".join("%.0f" % ((b - a) / 1e3) for a, b in zip(per_panel[:-1], per_panel[1:])))
+    for r in rows:
+        q = queues.setdefault(r["q"], "q%d" % (len(queues) + 1))
+        print("%9.1f %9.1f %7.1f  %s %s %d" % ((r["s"] - t0) / 1e3, (r["e"] - t0) / 1e3, (r["e"] - r["s"]) / 1e3, q,
+                                             short(r["name"]), r["wg"]))
+
+
+if __name__ == "__main__":
+    main()
