@@ -298,3 +298,26 @@ def test_dense_golden_fixtures(dev, golden_dir):
         xsd = dev.to_device(xs, torch.float64, "cuda")
         m = dev.predict_mean(xd, alpha, xsd, ell, sf2, None)
         assert _relerr(m.cpu().numpy(), g[tag + "_mean"]) < 1e-9
+
+
+def test_hip_posterior_agrees_with_scikit_learn(dev, golden_dir):
+    """The HIP path held directly to the scikit-learn fixtures (an implementation of the same exact
+    GP that is independent of this repository's oracle; tests/golden/make_sklearn_golden.py)."""
+    g = np.load(os.path.join(golden_dir, "sklearn_gp.npz"))
+    for tag in [str(t) for t in g["cases"]]:
+        x, y, xs = g[tag + "_x"], g[tag + "_y"], g[tag + "_xs"]
+        ell, sf2, noise = (float(v) for v in g[tag + "_hyp"])
+        n, ns = x.shape[0], xs.shape[0]
+        xd, yd, xsd = (dev.to_device(a, torch.float64, "cuda") for a in (x, y, xs))
+        kbuf = dev.rbf_gram(xd, ell, sf2, noise, lower_only=True)
+        ws, info = dev.potrf(kbuf, n)
+        assert int(info.item()) == 0
+        alpha = yd.clone()
+        z = dev.potrs(kbuf, n, ws, alpha, want_z=True)
+        w = dev.rbf_cross(xsd, xd, ell, sf2)
+        dev.trsm_rows(kbuf, n, ws, w, ns)
+        mean = torch.zeros((ns, 2), dtype=torch.float64, device="cuda")
+        var = torch.zeros(ns, dtype=torch.float64, device="cuda")
+        dev.predict_from_w(w, ns, n, z, sf2, 0.0, None, mean, var)
+        np.testing.assert_allclose(mean.cpu().numpy(), g[tag + "_mean"], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(var.cpu().numpy(), g[tag + "_var"], rtol=1e-5, atol=1e-8)

@@ -110,3 +110,22 @@ def test_non_pd_reports_lapack_info():
     assert info == 2
     with pytest.raises(np.linalg.LinAlgError):
         oracle.block_fit(x, np.zeros((3, 2)), 1.0, 1.0, 0.0)
+
+
+def test_dense_oracle_agrees_with_scikit_learn(golden_dir):
+    """Independent cross-check of the PARITY-UNPINNED dense oracle (GPy, the reference's backend at
+    RegressionInput.py:58-67, is absent): scikit-learn's exact GP with fixed hyper-parameters on the
+    same arrays (fixtures written by tests/golden/make_sklearn_golden.py, n in {64, 257, 512},
+    d in {1, 2}, two outputs sharing one kernel).  Two independent implementations of Rasmussen &
+    Williams Alg. 2.1 agree to rounding; the reference's own numbers stay unavailable."""
+    g = np.load(os.path.join(golden_dir, "sklearn_gp.npz"))
+    for tag in [str(t) for t in g["cases"]]:
+        x, y, xs = g[tag + "_x"], g[tag + "_y"], g[tag + "_xs"]
+        ell, sf2, noise = g[tag + "_hyp"]
+        fit = oracle.block_fit(x, y, ell, sf2, noise)
+        mean, var = oracle.block_predict(x, fit, xs, ell, sf2, True)
+        np.testing.assert_allclose(mean, g[tag + "_mean"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(var, g[tag + "_var"], rtol=1e-6, atol=1e-9)
+        # log marginal likelihood: sklearn sums the outputs' likelihoods, as oracle.gp_lml_and_grad does
+        lml, _ = oracle.gp_lml_and_grad(x, y, ell, sf2, noise)
+        np.testing.assert_allclose(lml, float(g[tag + "_lml"]), rtol=1e-9)
