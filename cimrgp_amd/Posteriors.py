@@ -18,6 +18,10 @@ from . import device as dev
 NOISE_FRACTION = 0.01    # RegressionInput.py:62: labels.var() * 0.01
 NOISE_FLOOR = 1e-8       # x sf: keeps a constant-target block positive definite
 
+#: equal-sized blocks of a layer up to this size are factored as ONE batch (same launches, grid.y =
+#: block); larger blocks fill the machine on their own and keep the look-ahead schedule
+BATCH_MAX_N = int(os.environ.get("CIMRGP_BATCH_MAX_N", "8192"))
+
 # ---- independent blocks of one layer run concurrently (the reference's independent-over-l loop,
 # Posteriors.py:35-59): a small pool of streams per device; blocks are dealt round-robin.
 _POOLS = {}
@@ -183,8 +187,21 @@ class DensePosterior(object):
         regions = list(regions)
         if not regions:
             return
-        fan = _Fanout(y_mean[regions[0]].device, len(regions), max(int(x[l].shape[0]) for l in regions))
+        # equal-sized small blocks: one batch per size (a uniform index set has at most two sizes per
+        # layer, the last region taking the remainder, IndexSetGenerator.py:51-65)
+        by_size = {}
         for l in regions:
+            by_size.setdefault(int(x[l].shape[0]), []).append(l)
+        single = []
+        for n_l, group in by_size.items():
+            if len(group) >= 2 and n_l <= BATCH_MAX_N:
+                self._fit_batched(group, y_mean, x, f_bar, train_out, shared_bias, shared_noise, keep_factors)
+            else:
+                single.extend(group)
+        if not single:
+            return
+        fan = _Fanout(y_mean[single[0]].device, len(single), max(int(x[l].shape[0]) for l in single))
+        for l in single:
             with torch.cuda.stream(fan.stream()):
                 blk = DenseBlock(x[l], self.kernel)
                 blk.fit(y_mean[l], f_bar[l], train_out[l], shared_bias, shared_noise, keep_factor=keep_factors)
@@ -192,6 +209,54 @@ class DensePosterior(object):
                     blk.hand_over_to(fan.main)
             self.blocks[l] = blk
         fan.join()
+
+    def _fit_batched(self, group, y_mean, x, f_bar, train_out, shared_bias, shared_noise, keep_factors):
+        """Fit ``group`` (regions of equal size) with ONE batched factorisation and ONE batched
+        backward solve: the matrices live in one arena (batch x n x ld) and every kernel of the panel
+        sweep is launched once for all of them (cimrgp_potrf_rows_batched)."""
+        k = self.kernel
+        n = int(x[group[0]].shape[0])
+        q = self.dy
+        device, dtype = y_mean[group[0]].device, y_mean[group[0]].dtype
+        nb = len(group)
+        ld = dev.padded_ld(n)
+        karena = torch.empty((nb, n, ld), dtype=dtype, device=device)
+        ws_bytes = (dev.potrf_workspace_bytes(n, dtype) + 15) // 16 * 16
+        ws_arena = torch.empty((nb, max(ws_bytes, 16)), dtype=torch.uint8, device=device)
+        info = torch.zeros(nb, dtype=torch.int32, device=device)
+        ldq = dev.padded_ld(n)
+        rows = torch.empty((nb, q, ldq), dtype=dtype, device=device)
+        blocks, resid = [], []
+        for i, l in enumerate(group):
+            blk = DenseBlock(x[l], k)
+            stats = None
+            if shared_bias is None or (shared_noise is None and k.noise is None):
+                stats = dev.block_stats(y_mean[l], f_bar[l])
+            blk.bias = stats[:q] if shared_bias is None else shared_bias
+            if k.noise is not None:
+                blk.noise = torch.full((1,), k.noise, dtype=dtype, device=device)
+            elif shared_noise is not None:
+                blk.noise = shared_noise
+            else:
+                blk.noise = dev.noise_from_stats(stats, q, NOISE_FRACTION, NOISE_FLOOR * k.sf)
+            r = dev.residual(y_mean[l], f_bar[l], blk.bias)
+            dev.rbf_gram(blk.x, k.l, k.sf, 0.0, lower_only=True, out=karena[i])
+            dev.add_diag(karena[i], n, blk.noise)
+            blocks.append(blk)
+            resid.append(r)
+        rows[:, :, :n] = torch.stack(resid).transpose(1, 2)
+        # the targets ride through the factorisation as q extra rows per block: z = L^-1 r
+        dev.potrf_rows_batched(karena, n, ld, ws_arena, info, rows, q, ldq)
+        z = rows[:, :, :n].transpose(1, 2).contiguous()
+        alpha = dev.solve_lt_batched(karena, n, ld, ws_arena, z.clone())
+        for i, l in enumerate(group):
+            blk = blocks[i]
+            blk.info = info[i:i + 1]
+            blk.alpha = alpha[i]
+            if keep_factors:
+                blk.lbuf, blk.ws, blk.z = karena[i], ws_arena[i], z[i]
+            dev.train_mean(resid[i], blk.alpha, blk.bias, blk.noise, train_out[l], accumulate=True)
+            self.blocks[l] = blk
 
     @staticmethod
     def _whole_layer(views):

@@ -115,6 +115,52 @@ int cimrgp_potrf_rows(int dtype, void* k_dev, int64_t n, int64_t ldk, void* work
              potrf_run<double>((double*)k_dev, n, ldk, (double*)workspace_dev, info_dev, (double*)b_dev, m, ldb, S(stream)));
 }
 
+int cimrgp_potrf_rows_batched(int dtype, void* k_dev, int64_t n, int64_t ldk, int64_t k_stride, void* workspace_dev,
+                              size_t workspace_stride_bytes, int32_t* info_dev, void* b_dev, int64_t m, int64_t ldb,
+                              int64_t b_stride, int batch, void* stream)
+{
+    const char* fn = "cimrgp_potrf_rows_batched";
+    CIMRGP_REQUIRE(k_dev && workspace_dev && info_dev, fn, "null pointer");
+    CIMRGP_REQUIRE(batch >= 1, fn, "batch must be >= 1");
+    CIMRGP_REQUIRE(n >= 0 && m >= 0 && ldk >= n && (m == 0 || (b_dev && ldb >= n)), fn, "bad dimensions");
+    CIMRGP_REQUIRE(dtype == CIMRGP_F32 || dtype == CIMRGP_F64, fn, "unknown dtype");
+    CIMRGP_REQUIRE(ld_ok(dtype, ldk) && (m == 0 || ld_ok(dtype, ldb)), fn, "leading dimensions must be multiples of 16 bytes");
+    CIMRGP_REQUIRE(aligned16(k_dev) && aligned16(workspace_dev) && aligned16(b_dev), fn, "pointers must be 16-byte aligned");
+    CIMRGP_REQUIRE(k_stride >= n * ldk - (ldk - n) && ld_ok(dtype, k_stride), fn, "matrix stride too small or misaligned");
+    CIMRGP_REQUIRE(m == 0 || (b_stride >= m * ldb - (ldb - n) && ld_ok(dtype, b_stride)), fn, "row-block stride too small or misaligned");
+    CIMRGP_REQUIRE(workspace_stride_bytes >= cimrgp_potrf_workspace_bytes(dtype, n) && workspace_stride_bytes % 16 == 0, fn,
+                   "workspace stride too small or misaligned");
+    if (n == 0) return check_hip(hipMemsetAsync(info_dev, 0, sizeof(int32_t) * (size_t)batch, S(stream)), fn, "memset");
+    PotrfBatch bt;
+    bt.count = batch;
+    bt.sk = k_stride;
+    bt.sws = (int64_t)(workspace_stride_bytes / esize(dtype));
+    bt.sb = b_stride;
+    DISPATCH(dtype, fn,
+             potrf_batched_run<float>((float*)k_dev, n, ldk, (float*)workspace_dev, info_dev, (float*)b_dev, m, ldb, bt, S(stream)),
+             potrf_batched_run<double>((double*)k_dev, n, ldk, (double*)workspace_dev, info_dev, (double*)b_dev, m, ldb, bt,
+                                       S(stream)));
+}
+
+int cimrgp_solve_lt_batched(int dtype, const void* l_dev, int64_t n, int64_t ldl, int64_t l_stride, const void* workspace_dev,
+                            size_t workspace_stride_bytes, void* z_dev, int q, void* scratch_dev, int batch, void* stream)
+{
+    const char* fn = "cimrgp_solve_lt_batched";
+    CIMRGP_REQUIRE(l_dev && workspace_dev && z_dev && scratch_dev, fn, "null pointer");
+    CIMRGP_REQUIRE(batch >= 1, fn, "batch must be >= 1");
+    CIMRGP_REQUIRE(n >= 0 && ldl >= n, fn, "bad dimensions");
+    CIMRGP_REQUIRE(workspace_stride_bytes >= cimrgp_potrf_workspace_bytes(dtype, n), fn, "workspace stride too small");
+    PotrfBatch bt;
+    bt.count = batch;
+    bt.sk = l_stride;
+    bt.sws = (int64_t)(workspace_stride_bytes / esize(dtype));
+    DISPATCH(dtype, fn,
+             potrs_run<float>((const float*)l_dev, n, ldl, (const float*)workspace_dev, (float*)z_dev, q, nullptr,
+                              (float*)scratch_dev, true, S(stream), bt),
+             potrs_run<double>((const double*)l_dev, n, ldl, (const double*)workspace_dev, (double*)z_dev, q, nullptr,
+                               (double*)scratch_dev, true, S(stream), bt));
+}
+
 int cimrgp_potrs(int dtype, const void* l_dev, int64_t n, int64_t ldl, const void* workspace_dev, void* rhs_dev, int q,
                  void* z_dev, void* scratch_dev, void* stream)
 {

@@ -104,13 +104,19 @@ template <> __device__ __forceinline__ uint4 neg_chunk<float>(uint4 v)
 // potrf.hip
 template <typename T> int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m, int64_t ldb,
                                     hipStream_t st);
+// `batch` equal-sized factorisations in the same launches (strides in elements / ints)
+struct PotrfBatch { int count = 1; int64_t sk = 0, sws = 0, sb = 0; };
+template <typename T> int potrf_batched_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m, int64_t ldb,
+                                            PotrfBatch bt, hipStream_t st);
 template <typename T> int solve_rows_run(const T* l, int64_t n, int64_t ld, const T* ws, T* b, int64_t m,
                                          int64_t ldb, hipStream_t st);
 int profile_begin();
 int profile_collect(double* total_ms, double* total_flops, int64_t* launches);
 // gemm_nt.hip
+// A batch of independent products in one launch (equal shapes; element strides between problems).
+struct GemmBatch { int count = 1; int64_t sc = 0, sa = 0, sb = 0; };
 template <typename T> int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t ldb,
-                                      int64_t m, int64_t n, int k, bool lower, hipStream_t st);
+                                      int64_t m, int64_t n, int k, bool lower, hipStream_t st, GemmBatch bt = GemmBatch());
 
 // gram.hip
 template <typename T> int rbf_gram_run(const T* xa, int64_t na, const T* xb, int64_t nb, int d, double ell, double sf2,
@@ -119,7 +125,7 @@ template <typename T> int predict_mean_run(const T* x, int64_t n, int d, const T
                                            double ell, double sf2, const T* bias, T* mean, int accumulate, hipStream_t st);
 // solve.hip
 template <typename T> int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* z_out, T* scratch,
-                                    bool backward_only, hipStream_t st);
+                                    bool backward_only, hipStream_t st, PotrfBatch bt = PotrfBatch());
 template <typename T> int predict_from_w_run(const T* w, int64_t ns, int64_t n, int64_t ldw, const T* z, int q, double sf2,
                                              double extra, const T* extra_dev, const T* bias, T* mean, T* var, int accumulate,
                                              hipStream_t st);

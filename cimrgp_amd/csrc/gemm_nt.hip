@@ -196,10 +196,14 @@ __global__ __launch_bounds__(256, 2)
 void k_gemm_nt_sub(T* __restrict__ C, int64_t ldc,
                    const T* __restrict__ A, int64_t lda,
                    const T* __restrict__ B, int64_t ldb,
-                   int M, int N, int K, int tiles_n)
+                   int M, int N, int K, int tiles_n, int64_t sc, int64_t sa, int64_t sb)
 {
     constexpr int GT = 32 * W;
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * GT * LROW];
+    // batch of independent products (blocks of one layer): blockIdx.y selects the problem
+    C += (int64_t)blockIdx.y * sc;
+    A += (int64_t)blockIdx.y * sa;
+    B += (int64_t)blockIdx.y * sb;
     int ti, tj;
     if (LOWER) {
         const int id = blockIdx.x;
@@ -220,24 +224,26 @@ void k_gemm_nt_sub(T* __restrict__ C, int64_t ldc,
 
 template <typename T, int W>
 static int gemm_launch(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t ldb,
-                       int64_t m, int64_t n, int k, bool lower, hipStream_t st)
+                       int64_t m, int64_t n, int k, bool lower, hipStream_t st, const GemmBatch& bt)
 {
     const char* fn = "gemm_nt_sub";
     constexpr int GT = 32 * W;
     const int64_t tm = (m + GT - 1) / GT, tn = (n + GT - 1) / GT;
     const int64_t tiles = lower ? tm * (tm + 1) / 2 : tm * tn;
     CIMRGP_REQUIRE(tiles < (1ll << 31), fn, "grid too large");
-    if (lower) hipLaunchKernelGGL((k_gemm_nt_sub<T, true, W>), dim3((unsigned)tiles), dim3(256), 0, st,
-                                  c, ldc, a, lda, b, ldb, (int)m, (int)n, k, (int)tn);
-    else       hipLaunchKernelGGL((k_gemm_nt_sub<T, false, W>), dim3((unsigned)tiles), dim3(256), 0, st,
-                                  c, ldc, a, lda, b, ldb, (int)m, (int)n, k, (int)tn);
+    CIMRGP_REQUIRE(bt.count >= 1 && bt.count < 65536, fn, "batch count out of range");
+    const dim3 grid((unsigned)tiles, (unsigned)bt.count);
+    if (lower) hipLaunchKernelGGL((k_gemm_nt_sub<T, true, W>), grid, dim3(256), 0, st,
+                                  c, ldc, a, lda, b, ldb, (int)m, (int)n, k, (int)tn, bt.sc, bt.sa, bt.sb);
+    else       hipLaunchKernelGGL((k_gemm_nt_sub<T, false, W>), grid, dim3(256), 0, st,
+                                  c, ldc, a, lda, b, ldb, (int)m, (int)n, k, (int)tn, bt.sc, bt.sa, bt.sb);
     CIMRGP_LAUNCH_CHECK(fn);
     return 0;
 }
 
 template <typename T>
 int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t ldb,
-                int64_t m, int64_t n, int k, bool lower, hipStream_t st)
+                int64_t m, int64_t n, int k, bool lower, hipStream_t st, GemmBatch bt)
 {
     const char* fn = "gemm_nt_sub";
     if (m <= 0 || n <= 0 || k <= 0) return 0;
@@ -248,18 +254,19 @@ int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t 
     // fewer than ~3 workgroups per CU with 128-tiles: use 64-tiles (4x the workgroups, 1/4 the work
     // each; measured sweep of the switch point inside the factorisation at N = 8192:
     // 256/512/768/1024/1536 tiles -> 91.3/93.5/94.2/91.9/90.6 posteriors/s)
-    const int64_t t128 = ((m + 127) / 128) * ((n + 127) / 128) / (lower ? 2 : 1);
+    // (a batch multiplies the number of workgroups: choose the tile for the whole launch)
+    const int64_t t128 = ((m + 127) / 128) * ((n + 127) / 128) / (lower ? 2 : 1) * bt.count;
     // tiny updates on the factorisation's critical path (the 256 x 256 diagonal block): 32-tiles, so
     // that the K loop of a tile is 1/4 as long and ~36 compute units share it instead of 10
-    const int64_t t64 = ((m + 63) / 64) * ((n + 63) / 64) / (lower ? 2 : 1);
-    if (t64 < 32) return gemm_launch<T, 1>(c, ldc, a, lda, b, ldb, m, n, k, lower, st);
-    if (t128 < 768) return gemm_launch<T, 2>(c, ldc, a, lda, b, ldb, m, n, k, lower, st);
-    return gemm_launch<T, 4>(c, ldc, a, lda, b, ldb, m, n, k, lower, st);
+    const int64_t t64 = ((m + 63) / 64) * ((n + 63) / 64) / (lower ? 2 : 1) * bt.count;
+    if (t64 < 32) return gemm_launch<T, 1>(c, ldc, a, lda, b, ldb, m, n, k, lower, st, bt);
+    if (t128 < 768) return gemm_launch<T, 2>(c, ldc, a, lda, b, ldb, m, n, k, lower, st, bt);
+    return gemm_launch<T, 4>(c, ldc, a, lda, b, ldb, m, n, k, lower, st, bt);
 }
 
 template int gemm_nt_sub<double>(double*, int64_t, const double*, int64_t, const double*, int64_t,
-                                 int64_t, int64_t, int, bool, hipStream_t);
+                                 int64_t, int64_t, int, bool, hipStream_t, GemmBatch);
 template int gemm_nt_sub<float>(float*, int64_t, const float*, int64_t, const float*, int64_t,
-                                int64_t, int64_t, int, bool, hipStream_t);
+                                int64_t, int64_t, int, bool, hipStream_t, GemmBatch);
 
 }  // namespace cimrgp

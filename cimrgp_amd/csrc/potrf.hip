@@ -286,8 +286,13 @@ static __device__ __forceinline__ Mx<float>::acc_t mfma_k4(float a, float b, Mx<
 template <typename T>
 __global__ __launch_bounds__(DG_NT)
 void k_diag64(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow, int kprev,
-              T* __restrict__ inv, int32_t* info, int col_base)
+              T* __restrict__ inv, int32_t* info, int col_base, int64_t sk = 0, int64_t sws = 0)
 {
+    // batch of independent factorisations (blocks of one layer): blockIdx.y selects the matrix
+    D += (int64_t)blockIdx.y * sk;
+    Lrow += (int64_t)blockIdx.y * sk;
+    inv += (int64_t)blockIdx.y * sws;
+    info += blockIdx.y;
     using X = Mx<T>;
     using TL = Tile64<T>;
     using acc_t = typename X::acc_t;
@@ -565,8 +570,13 @@ template <typename T>
 __global__ __launch_bounds__(256)
 void k_trsm64(T* __restrict__ P1, int64_t ld1, int M1, int nb1,
               T* __restrict__ P2, int64_t ld2, int M2,
-              int kw, int kprev, const T* __restrict__ Lrow, int64_t ldl, const T* __restrict__ invL)
+              int kw, int kprev, const T* __restrict__ Lrow, int64_t ldl, const T* __restrict__ invL,
+              int64_t sk = 0, int64_t sws = 0, int64_t sb = 0)
 {
+    P1 += (int64_t)blockIdx.y * sk;                  // batch: see k_diag64
+    if (P2) P2 += (int64_t)blockIdx.y * sb;
+    Lrow += (int64_t)blockIdx.y * sk;
+    invL += (int64_t)blockIdx.y * sws;
     const bool second = (int)blockIdx.x >= nb1;
     T* P = second ? P2 : P1;
     const int64_t ldp = second ? ld2 : ld1;
@@ -599,8 +609,9 @@ void k_trsm256(T* __restrict__ P, int64_t ldp, int M, int w, const T* __restrict
 // row r = column r of L_pp^-1), stored 256 x 256 row-major per panel.
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ void k_invT_init(T* __restrict__ invT, int n)
+__global__ void k_invT_init(T* __restrict__ invT, int n, int64_t sws = 0)
 {
+    invT += (int64_t)blockIdx.z * sws;
     const int p = blockIdx.y;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;          // element of the 256 x 256 block
     const int r = e >> 8, c = e & 255;
@@ -610,8 +621,12 @@ __global__ void k_invT_init(T* __restrict__ invT, int n)
 
 template <typename T>
 __global__ __launch_bounds__(256)
-void k_invT_step(T* __restrict__ invT, const T* __restrict__ L, int64_t ld, int n, const T* __restrict__ inv64, int s)
+void k_invT_step(T* __restrict__ invT, const T* __restrict__ L, int64_t ld, int n, const T* __restrict__ inv64, int s,
+                 int64_t sk = 0, int64_t sws = 0)
 {
+    invT += (int64_t)blockIdx.z * sws;
+    L += (int64_t)blockIdx.z * sk;
+    inv64 += (int64_t)blockIdx.z * sws;
     const int p = blockIdx.y;
     const int k0 = p * CIMRGP_NB, c0 = k0 + SB * s;
     const int kw = min(SB, n - c0);
@@ -679,10 +694,11 @@ static int rows_panel_step(T* b, int64_t ldb, int64_t m, const T* lmat, int64_t 
 
 template <typename T, bool FACTOR>
 static int panel_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info,
-                       T* b, int64_t m, int64_t ldb, hipStream_t st)
+                       T* b, int64_t m, int64_t ldb, hipStream_t st, PotrfBatch bt = PotrfBatch())
 {
     const char* fn = FACTOR ? "cimrgp_potrf" : "cimrgp_trsm_rows";
     const bool rows = (b != nullptr && m > 0);
+    const unsigned nbatch = (unsigned)bt.count;        // equal-sized problems in the same launches (grid.y)
     PanelGroup rows_grp;
     for (int64_t k0 = 0; k0 < n; k0 += CIMRGP_NB) {
         const int64_t w = (n - k0 < CIMRGP_NB) ? (n - k0) : CIMRGP_NB;
@@ -699,33 +715,35 @@ static int panel_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info,
             T* inv = ws + (c0 / SB) * (SB * SB);
             const T* lrow = kmat + c0 * ld + k0;   // rows of the diagonal block, earlier panel columns
             if (FACTOR) {
-                hipLaunchKernelGGL((k_diag64<T>), dim3(1), dim3(DG_NT), 0, st,
-                                   kmat + c0 * ld + c0, ld, sw, lrow, kprev, inv, info, (int)c0);
+                hipLaunchKernelGGL((k_diag64<T>), dim3(1, nbatch), dim3(DG_NT), 0, st,
+                                   kmat + c0 * ld + c0, ld, sw, lrow, kprev, inv, info, (int)c0, bt.sk, bt.sws);
                 CIMRGP_LAUNCH_CHECK(fn);
             }
             const int64_t m1 = FACTOR ? (n - pc) : 0;
             const int nb1 = (int)((m1 + TR - 1) / TR);
             const int nb2 = rows ? (int)((m + TR - 1) / TR) : 0;
             if (nb1 + nb2 > 0) {
-                hipLaunchKernelGGL((k_trsm64<T>), dim3((unsigned)(nb1 + nb2)), dim3(256), 0, st,
+                hipLaunchKernelGGL((k_trsm64<T>), dim3((unsigned)(nb1 + nb2), nbatch), dim3(256), 0, st,
                                    kmat + pc * ld + c0, ld, (int)m1, nb1,
                                    rows ? b + c0 : nullptr, ldb, rows ? (int)m : 0,
-                                   sw, kprev, lrow, ld, (const T*)inv);
+                                   sw, kprev, lrow, ld, (const T*)inv, bt.sk, bt.sws, bt.sb);
                 CIMRGP_LAUNCH_CHECK(fn);
             }
         }
         if (n > k1) {
             if (FACTOR) {
                 const double mm = (double)(n - k1);
-                TrailRec* rec = rec_open(st, mm * (mm + 1.0) * (double)w);   // lower SYRK: M(M+1)K flop
+                TrailRec* rec = rec_open(st, mm * (mm + 1.0) * (double)w * (double)bt.count);   // lower SYRK: M(M+1)K flop
+                GemmBatch gb; gb.count = bt.count; gb.sc = gb.sa = gb.sb = bt.sk;
                 int rc = gemm_nt_sub<T>(kmat + k1 * ld + k1, ld, kmat + k1 * ld + k0, ld,
-                                        kmat + k1 * ld + k0, ld, n - k1, n - k1, (int)w, true, st);
+                                        kmat + k1 * ld + k0, ld, n - k1, n - k1, (int)w, true, st, gb);
                 if (rec) (void)hipEventRecord(rec->stop, st);
                 if (rc) return rc;
             }
             if (rows) {
+                GemmBatch gb; gb.count = bt.count; gb.sc = gb.sa = bt.sb; gb.sb = bt.sk;
                 int rc = gemm_nt_sub<T>(b + k1, ldb, b + k0, ldb, kmat + k1 * ld + k0, ld,
-                                        m, n - k1, (int)w, false, st);
+                                        m, n - k1, (int)w, false, st, gb);
                 if (rc) return rc;
             }
         }
@@ -857,16 +875,18 @@ int factor_panel(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, int64_t k
 
 // Workspace layout: [ceil(n/64) slabs of 64x64 inverses][ceil(n/256) blocks of 256x256 invT].
 template <typename T>
-static int build_invT(const T* kmat, int64_t n, int64_t ld, T* ws, hipStream_t st)
+static int build_invT(const T* kmat, int64_t n, int64_t ld, T* ws, hipStream_t st, PotrfBatch bt = PotrfBatch())
 {
     const char* fn = "cimrgp_potrf";
     const int64_t nslab = (n + SB - 1) / SB, npan = (n + CIMRGP_NB - 1) / CIMRGP_NB;
     T* invT = ws + nslab * (SB * SB);
-    hipLaunchKernelGGL((k_invT_init<T>), dim3(CIMRGP_NB * CIMRGP_NB / 256, (unsigned)npan), dim3(256), 0, st, invT, (int)n);
+    const unsigned nbatch = (unsigned)bt.count;
+    hipLaunchKernelGGL((k_invT_init<T>), dim3(CIMRGP_NB * CIMRGP_NB / 256, (unsigned)npan, nbatch), dim3(256), 0, st,
+                       invT, (int)n, bt.sws);
     CIMRGP_LAUNCH_CHECK(fn);
     for (int s = 0; s < CIMRGP_NB / SB; ++s) {
-        hipLaunchKernelGGL((k_invT_step<T>), dim3(CIMRGP_NB / TR, (unsigned)npan), dim3(256), 0, st,
-                           invT, kmat, ld, (int)n, (const T*)ws, s);
+        hipLaunchKernelGGL((k_invT_step<T>), dim3(CIMRGP_NB / TR, (unsigned)npan, nbatch), dim3(256), 0, st,
+                           invT, kmat, ld, (int)n, (const T*)ws, s, bt.sk, bt.sws);
         CIMRGP_LAUNCH_CHECK(fn);
     }
     return 0;
@@ -1072,6 +1092,20 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     return build_invT<T>(k, n, ld, ws, st);
 }
 
+// `bt.count` equal-sized factorisations (the blocks of one layer) in the SAME launches: every
+// kernel of the one-queue sweep runs with grid.y = count, so a layer of many small blocks costs the
+// host one block's worth of launches and the device sees all the blocks' panel chains side by side.
+template <typename T>
+int potrf_batched_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m, int64_t ldb, PotrfBatch bt,
+                      hipStream_t st)
+{
+    if (bt.count < 1 || bt.count >= 65536) return fail("cimrgp_potrf_batched", "batch count out of range");
+    hipError_t e = hipMemsetAsync(info, 0, sizeof(int32_t) * (size_t)bt.count, st);
+    if (e != hipSuccess) return check_hip(e, "cimrgp_potrf_batched", "hipMemsetAsync(info)");
+    int rc = panel_sweep<T, true>(k, n, ld, ws, info, b, m, ldb, st, bt);
+    return rc ? rc : build_invT<T>(k, n, ld, ws, st, bt);
+}
+
 template <typename T>
 int solve_rows_run(const T* l, int64_t n, int64_t ld, const T* ws, T* b, int64_t m, int64_t ldb, hipStream_t st)
 {
@@ -1080,6 +1114,8 @@ int solve_rows_run(const T* l, int64_t n, int64_t ld, const T* ws, T* b, int64_t
 
 template int potrf_run<double>(double*, int64_t, int64_t, double*, int32_t*, double*, int64_t, int64_t, hipStream_t);
 template int potrf_run<float>(float*, int64_t, int64_t, float*, int32_t*, float*, int64_t, int64_t, hipStream_t);
+template int potrf_batched_run<double>(double*, int64_t, int64_t, double*, int32_t*, double*, int64_t, int64_t, PotrfBatch, hipStream_t);
+template int potrf_batched_run<float>(float*, int64_t, int64_t, float*, int32_t*, float*, int64_t, int64_t, PotrfBatch, hipStream_t);
 template int solve_rows_run<double>(const double*, int64_t, int64_t, const double*, double*, int64_t, int64_t, hipStream_t);
 template int solve_rows_run<float>(const float*, int64_t, int64_t, const float*, float*, int64_t, int64_t, hipStream_t);
 

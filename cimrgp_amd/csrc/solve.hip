@@ -21,8 +21,11 @@ constexpr int MAXQ = 8;
 
 // (n x q) row-major  <->  (q x n)
 template <typename T>
-__global__ void k_transpose_nq(const T* __restrict__ src, T* __restrict__ dst, int64_t n, int q, int to_qn)
+__global__ void k_transpose_nq(const T* __restrict__ src, T* __restrict__ dst, int64_t n, int q, int to_qn,
+                               int64_t ssrc = 0, int64_t sdst = 0)
 {
+    src += (int64_t)blockIdx.y * ssrc;               // batch of independent solves: blockIdx.y selects the problem
+    dst += (int64_t)blockIdx.y * sdst;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n * q) return;
     if (to_qn) { const int64_t c = e / n, i = e - c * n; dst[e] = src[i * q + c]; }
@@ -134,8 +137,13 @@ void k_fwd_panel(const T* __restrict__ L, int64_t ld, int n, const T* __restrict
 template <typename T, int Q>
 __global__ __launch_bounds__(ST)
 void k_bwd_panel(const T* __restrict__ L, int64_t ld, int n, const T* __restrict__ invT,
-                 T* __restrict__ work, T* __restrict__ out, int q, int k0, int w)
+                 T* __restrict__ work, T* __restrict__ out, int q, int k0, int w,
+                 int64_t sk = 0, int64_t sws = 0, int64_t sscr = 0)
 {
+    L += (int64_t)blockIdx.y * sk;                   // batch: see k_transpose_nq
+    invT += (int64_t)blockIdx.y * sws;
+    work += (int64_t)blockIdx.y * sscr;
+    out += (int64_t)blockIdx.y * sscr;
     __shared__ T ws_[Q][PW];
     __shared__ T zs[Q][PW];
     __shared__ T red[16][Q][SB];
@@ -292,16 +300,21 @@ void k_predict_from_w(const T* __restrict__ W, int ns, int n, int64_t ldw, const
 
 template <typename T>
 int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* z_out, T* scratch,
-              bool backward_only, hipStream_t st)
+              bool backward_only, hipStream_t st, PotrfBatch bt)
 {
     const char* fn = "cimrgp_potrs";
     if (n <= 0) return 0;
+    CIMRGP_REQUIRE(bt.count == 1 || backward_only, fn, "only the backward half is batched");
+    CIMRGP_REQUIRE(bt.count >= 1 && bt.count < 65536, fn, "batch count out of range");
+    const unsigned nbatch = (unsigned)bt.count;
+    const int64_t sscr = (bt.count > 1) ? 2 * (int64_t)q * n : 0;     // scratch per problem: [work | res]
+    const int64_t srhs = (bt.count > 1) ? (int64_t)q * n : 0;         // right-hand sides per problem (n x q)
     CIMRGP_REQUIRE(q >= 1 && q <= MAXQ, fn, "number of right-hand sides must be in [1, 8]");
     CIMRGP_REQUIRE(n < (1ll << 31), fn, "matrix too large");
     T* work = scratch;             // (q x n) running right-hand side
     T* res  = scratch + q * n;     // (q x n) solved blocks
     const unsigned tg = (unsigned)((n * q + 255) / 256);
-    hipLaunchKernelGGL((k_transpose_nq<T>), dim3(tg), dim3(256), 0, st, (const T*)rhs, work, n, q, 1);
+    hipLaunchKernelGGL((k_transpose_nq<T>), dim3(tg, nbatch), dim3(256), 0, st, (const T*)rhs, work, n, q, 1, srhs, sscr);
     CIMRGP_LAUNCH_CHECK(fn);
     const T* invT = ws + ((n + SB - 1) / SB) * (SB * SB);
     for (int64_t k0 = 0; k0 < n && !backward_only; k0 += PW) {
@@ -324,11 +337,11 @@ int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* 
     for (int64_t k0 = last; k0 >= 0; k0 -= PW) {
         const int w = (int)((n - k0 < PW) ? (n - k0) : PW);
         const unsigned grid = (unsigned)((k0 + SB - 1) / SB);
-        CIMRGP_Q_SWITCH(q, hipLaunchKernelGGL((k_bwd_panel<T, QQ>), dim3(grid ? grid : 1), dim3(ST), 0, st, l, ld, (int)n,
-                                              invT, work, res, q, (int)k0, w));
+        CIMRGP_Q_SWITCH(q, hipLaunchKernelGGL((k_bwd_panel<T, QQ>), dim3(grid ? grid : 1, nbatch), dim3(ST), 0, st, l, ld, (int)n,
+                                              invT, work, res, q, (int)k0, w, bt.sk, bt.sws, sscr));
         CIMRGP_LAUNCH_CHECK(fn);
     }
-    hipLaunchKernelGGL((k_transpose_nq<T>), dim3(tg), dim3(256), 0, st, (const T*)res, rhs, n, q, 0);
+    hipLaunchKernelGGL((k_transpose_nq<T>), dim3(tg, nbatch), dim3(256), 0, st, (const T*)res, rhs, n, q, 0, sscr, srhs);
     CIMRGP_LAUNCH_CHECK(fn);
     return 0;
 }
@@ -347,8 +360,8 @@ int predict_from_w_run(const T* w, int64_t ns, int64_t n, int64_t ldw, const T* 
     return 0;
 }
 
-template int potrs_run<double>(const double*, int64_t, int64_t, const double*, double*, int, double*, double*, bool, hipStream_t);
-template int potrs_run<float>(const float*, int64_t, int64_t, const float*, float*, int, float*, float*, bool, hipStream_t);
+template int potrs_run<double>(const double*, int64_t, int64_t, const double*, double*, int, double*, double*, bool, hipStream_t, PotrfBatch);
+template int potrs_run<float>(const float*, int64_t, int64_t, const float*, float*, int, float*, float*, bool, hipStream_t, PotrfBatch);
 template int predict_from_w_run<double>(const double*, int64_t, int64_t, int64_t, const double*, int, double, double,
                                         const double*, const double*, double*, double*, int, hipStream_t);
 template int predict_from_w_run<float>(const float*, int64_t, int64_t, int64_t, const float*, int, double, double,

@@ -89,10 +89,12 @@ def rbf_cross(xa, xb, ell, sf2, out=None):
     return out
 
 
+def potrf_workspace_bytes(n, dtype):
+    return int(_lib.load().cimrgp_potrf_workspace_bytes(_DT[dtype], int(n)))
+
+
 def potrf_workspace(n, dtype, device):
-    lib = _lib.load()
-    nbytes = lib.cimrgp_potrf_workspace_bytes(_DT[dtype], int(n))
-    return torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
+    return torch.empty(max(potrf_workspace_bytes(n, dtype), 16), dtype=torch.uint8, device=device)
 
 
 def potrf(kbuf, n, ws=None, info=None):
@@ -118,6 +120,28 @@ def potrf_rows(kbuf, n, bbuf, m, ws=None, info=None):
     _lib.check(lib.cimrgp_potrf_rows(_DT[kbuf.dtype], _p(kbuf), int(n), kbuf.stride(0), _p(ws), ws.numel(),
                                      _p(info), _p(bbuf), int(m), bbuf.stride(0), _stream()), "cimrgp_potrf_rows")
     return ws, info
+
+
+def potrf_rows_batched(karena, n, ld, ws_arena, info, barena=None, m=0, ldb=0):
+    """``batch`` equal-sized factorisations in the same launches.  karena: (batch, n, ld) tensor,
+    ws_arena: (batch, ws_bytes) uint8, info: (batch,) int32, barena: (batch, m, ldb) carried rows."""
+    lib = _lib.load()
+    batch = karena.shape[0]
+    _lib.check(lib.cimrgp_potrf_rows_batched(_DT[karena.dtype], _p(karena), int(n), int(ld), karena.stride(0), _p(ws_arena),
+                                             ws_arena.stride(0), _p(info), _p(barena), int(m), int(ldb),
+                                             0 if barena is None else barena.stride(0), int(batch), _stream()),
+               "cimrgp_potrf_rows_batched")
+
+
+def solve_lt_batched(karena, n, ld, ws_arena, z):
+    """Backward halves for a batch: z (batch, n, q) = L^-1 R is overwritten with alpha."""
+    lib = _lib.load()
+    batch, _, q = z.shape
+    scratch = torch.empty((batch, 2 * q * max(int(n), 1)), dtype=karena.dtype, device=karena.device)
+    _lib.check(lib.cimrgp_solve_lt_batched(_DT[karena.dtype], _p(karena), int(n), int(ld), karena.stride(0), _p(ws_arena),
+                                           ws_arena.stride(0), _p(z), int(q), _p(scratch), int(batch), _stream()),
+               "cimrgp_solve_lt_batched")
+    return z
 
 
 def solve_lt(lbuf, n, ws, z):

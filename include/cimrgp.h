@@ -87,6 +87,17 @@ int cimrgp_potrf_rows(int dtype, void* k_dev, int64_t n, int64_t ldk,
                       int32_t* info_dev, void* b_dev, int64_t m, int64_t ldb,
                       void* stream);
 
+/* `batch` equal-sized factorisations -- the blocks of one layer (independent over regions,
+ * Posteriors.py:35-59) -- in the SAME kernel launches: matrix i starts k_stride elements after
+ * matrix i-1 (likewise workspace_stride_bytes, b_stride), info_dev holds `batch` int32.  One queue
+ * (no look-ahead): a layer of many small blocks is launch- and latency-bound, and batching gives the
+ * host one block's worth of launches and the device all the blocks' panel chains side by side.
+ * b_dev may be NULL (m = 0). */
+int cimrgp_potrf_rows_batched(int dtype, void* k_dev, int64_t n, int64_t ldk, int64_t k_stride,
+                              void* workspace_dev, size_t workspace_stride_bytes,
+                              int32_t* info_dev, void* b_dev, int64_t m, int64_t ldb,
+                              int64_t b_stride, int batch, void* stream);
+
 /* ---- D3: alpha = (L L^T)^-1 R  for q right-hand sides ---------------------
  * Replaces the two triangular solves of GPy's posterior ("woodbury vector").
  * rhs_dev: (n x q) row-major, overwritten with alpha.  z_dev (optional, may
@@ -101,6 +112,12 @@ int cimrgp_potrs(int dtype, const void* l_dev, int64_t n, int64_t ldl,
 int cimrgp_solve_lt(int dtype, const void* l_dev, int64_t n, int64_t ldl,
                     const void* workspace_dev, void* z_dev, int q,
                     void* scratch_dev, void* stream);
+
+/* The backward half for `batch` equal-sized factors in the same launches: z_dev holds batch
+ * blocks of (n x q), scratch_dev batch blocks of 2*q*n elements. */
+int cimrgp_solve_lt_batched(int dtype, const void* l_dev, int64_t n, int64_t ldl, int64_t l_stride,
+                            const void* workspace_dev, size_t workspace_stride_bytes,
+                            void* z_dev, int q, void* scratch_dev, int batch, void* stream);
 
 /* Row-wise triangular solve with many right-hand sides (MFMA):
  *   B <- B L^-T      B: (m x n) row-major, ldb >= n,  i.e. row i of B becomes

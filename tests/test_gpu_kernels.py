@@ -321,3 +321,57 @@ def test_hip_posterior_agrees_with_scikit_learn(dev, golden_dir):
         dev.predict_from_w(w, ns, n, z, sf2, 0.0, None, mean, var)
         np.testing.assert_allclose(mean.cpu().numpy(), g[tag + "_mean"], rtol=1e-7, atol=1e-8)
         np.testing.assert_allclose(var.cpu().numpy(), g[tag + "_var"], rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("dt,tol", [("f64", 1e-10), ("f32", 5e-4)])
+@pytest.mark.parametrize("n,batch,m", [(1, 2, 0), (130, 3, 2), (1000, 4, 3), (2049, 2, 0)])
+def test_potrf_rows_batched_matches_single(dev, dt, tol, n, batch, m):
+    """``batch`` equal-sized factorisations in the same launches (blocks of one layer): each must equal
+    LAPACK on its own matrix, carried rows and backward solve included; a non-PD member reports its own
+    ``info`` without disturbing the others."""
+    tdt = getattr(torch, TDT[dt])
+    rng = np.random.default_rng(100 * n + batch)
+    ld = dev.padded_ld(n)
+    karena = torch.empty((batch, n, ld), dtype=tdt, device="cuda")
+    ws_bytes = (dev.potrf_workspace_bytes(n, tdt) + 15) // 16 * 16
+    ws_arena = torch.empty((batch, max(ws_bytes, 16)), dtype=torch.uint8, device="cuda")
+    info = torch.full((batch,), 7, dtype=torch.int32, device="cuda")
+    xs_, ks_ = [], []
+    for i in range(batch):
+        x = np.sort(rng.uniform(-2, 2, size=(n, 1)), axis=0)
+        xs_.append(x)
+        ks_.append(oracle.rbf_gram(x, None, 0.3 + 0.1 * i, 1.0, 0.05))
+        dev.rbf_gram(dev.to_device(x, tdt, "cuda"), 0.3 + 0.1 * i, 1.0, 0.05, lower_only=True, out=karena[i])
+    rows = bmat = None
+    if m:
+        bmat = rng.normal(size=(batch, m, n))
+        rows = torch.zeros((batch, m, ld), dtype=tdt, device="cuda")
+        rows[:, :, :n] = torch.from_numpy(bmat).to("cuda", tdt)
+    dev.potrf_rows_batched(karena, n, ld, ws_arena, info, rows, m, ld if m else 0)
+    assert info.cpu().tolist() == [0] * batch
+    for i in range(batch):
+        lref, _ = oracle.potrf_lower(ks_[i])
+        got = torch.tril(karena[i][:, :n]).double().cpu().numpy()
+        assert _relerr(got, lref) < tol
+        if m:
+            want = sla.solve_triangular(lref, bmat[i].T, lower=True).T
+            assert _relerr(rows[i][:, :n].double().cpu().numpy(), want) < 10 * tol
+    # batched backward halves against LAPACK
+    q = 2
+    zs = rng.normal(size=(batch, n, q))
+    z = torch.from_numpy(zs).to("cuda", tdt).contiguous()
+    dev.solve_lt_batched(karena, n, ld, ws_arena, z)
+    for i in range(batch):
+        lref, _ = oracle.potrf_lower(ks_[i])
+        want = sla.solve_triangular(lref, zs[i], lower=True, trans="T")
+        assert _relerr(z[i].double().cpu().numpy(), want) < 100 * tol
+    if n >= 130 and dt == "f64":
+        # member 1 made singular (two identical points, no noise): only ITS info is set
+        for i in range(batch):
+            x = xs_[i].copy()
+            if i == 1:
+                x[5] = x[4]
+            dev.rbf_gram(dev.to_device(x, tdt, "cuda"), 0.3, 1.0, 0.0 if i == 1 else 0.05, lower_only=True, out=karena[i])
+        dev.potrf_rows_batched(karena, n, ld, ws_arena, info)
+        got = info.cpu().tolist()
+        assert got[1] > 0 and all(g == 0 for j, g in enumerate(got) if j != 1)
