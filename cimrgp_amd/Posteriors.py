@@ -20,7 +20,7 @@ NOISE_FLOOR = 1e-8       # x sf: keeps a constant-target block positive definite
 
 #: equal-sized blocks of a layer up to this size are factored as ONE batch (same launches, grid.y =
 #: block); larger blocks fill the machine on their own and keep the look-ahead schedule
-BATCH_MAX_N = int(os.environ.get("CIMRGP_BATCH_MAX_N", "8192"))
+BATCH_MAX_N = int(os.environ.get("CIMRGP_BATCH_MAX_N", "16384"))
 
 # ---- independent blocks of one layer run concurrently (the reference's independent-over-l loop,
 # Posteriors.py:35-59): a small pool of streams per device; blocks are dealt round-robin.

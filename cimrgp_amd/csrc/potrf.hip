@@ -788,10 +788,12 @@ LookAhead* make_ctx(int dev)
     // for the latency-bound chain by running the MFMA-bound update kernels on queues whose CU
     // mask excludes them.  Mask bit b is CU b / 8 of XCD b % 8 (measured: a mask that thins out
     // ONE XCD slows a kernel by that XCD's loss, because workgroups are dealt round-robin to
-    // the XCDs).  Measured twice and rejected as a default: in round 1 the end-to-end time did
-    // not move (N = 8192: 7.77 vs 7.79 ms); in round 2, with every wide kernel moved off the chain
-    // queue, masked queues slowed the WHOLE step (94 -> 54 posteriors/s): hipExtStreamCreateWithCUMask
-    // makes blocking streams, which synchronise implicitly with the caller's default stream.
+    // the XCDs).  Measured and rejected as a default.  hipExtStreamCreateWithCUMask makes BLOCKING
+    // streams: with the caller on the legacy default stream (torch's default) they synchronise
+    // implicitly with everything the caller launches and slow the whole step (round 2, N = 8192:
+    // 95 -> 84 posteriors/s with R = 1).  With the caller on a non-blocking stream that cost is gone,
+    // and the gain is small (potrf 7.49 -> 7.38 ms, with 2050 carried rows 9.49 -> 9.36 ms at R = 2):
+    // the chain's wide links (panel solve, head update) need the whole machine and wait just the same.
     const char* env = getenv("CIMRGP_RESERVE_CUS");
     const int reserve = env ? atoi(env) : 0;
     hipDeviceProp_t prop;
@@ -913,7 +915,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     // Host threads whose streams share a context serialise their ENQUEUE (microseconds); distinct
     // caller streams have distinct contexts and enqueue concurrently.
     std::lock_guard<std::mutex> guard(la->enqueue);
-    if (!grow_events(la, (size_t)(7 * npanels + 8))) return fail("cimrgp_potrf", "hipEventCreate failed");
+    if (!grow_events(la, (size_t)(7 * npanels + 12))) return fail("cimrgp_potrf", "hipEventCreate failed");
     hipStream_t sp = la->side;
     hipStream_t sb = la->bulk ? la->bulk : st;         // bulk trailing updates
     size_t ne = 0;
@@ -938,13 +940,18 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     const int64_t single_tail_below = SINGLE_TAIL_BELOW;
     hipEvent_t ev_bulk_last = nullptr;                 // last thing queued on the bulk stream
     int64_t rows_next = 0;                             // first panel the carried rows have not seen yet
-    PanelGroup rows_grp;                               // carried rows: open group of panels whose far update is owed
     // Panel k0 is final (event ev_final): solve + update the carried rows.  They form their own
     // chain (panel p+1 of the rows needs panel p of the rows) that depends on the factorisation
-    // only through "panel k0 final", so it runs on a third queue and lags behind: nothing of it is
+    // only through "panel k0 final", so it runs on its own queues and lags behind: nothing of it is
     // issued while the trailing updates are still large (that phase is MFMA-bound and the rows
     // would only take compute units away from the critical path); from then on it fills the
     // compute units the latency-bound panel chain leaves idle.
+    // (Measured and rejected in round 2: cutting the rows into 2..4 slices on queues of their own so
+    // that their latency-bound chains overlap -- 9.5 -> 10.1 / 12.6 / 21 ms at N = 8192 with 2050 rows:
+    // more low-priority queues only add contention for the panel chain; 64-tile updates for the rows,
+    // whose workgroups retire four times as often: 94.8 -> 92.6 posteriors/s; an earlier or later
+    // start than 4608 trailing rows: 3072 / 5632 / 6656 / 8192 -> 89.2 / 94.3 / 91.6 / 89.5.)
+    PanelGroup rows_grp;                               // carried rows: open group of panels whose far update is owed
     auto rows_after_panel = [&](int64_t k0, int64_t k1, hipEvent_t ev_final) -> int {
         if (!rows) return 0;
         hipStream_t sq = la->rows;                     // always present (make_ctx: all queues or no context)
@@ -1079,7 +1086,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
         rc = rows_after_panel(k0, k1, ev_final);
         if (rc) return rc;
     }
-    if (rows && la->rows) {
+    if (rows) {
         hipEvent_t ev_rows_done = la->ev[ne++];
         CIMRGP_HIP_TRY(hipEventRecord(ev_rows_done, la->rows), "hipEventRecord");
         CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_rows_done, 0), "hipStreamWaitEvent");
