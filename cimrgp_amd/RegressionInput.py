@@ -71,13 +71,19 @@ class RegressionMethod(object):
 class GP_RBF(RegressionMethod):
     name = 'GP_RBF'
 
-    def __init__(self, lengthscale=1., variance=1., dtype='f64', device=None, optimize=True, max_iters=1000):
-        """``optimize=True`` (default) is the reference's behaviour: its ``_fit`` always calls
+    def __init__(self, lengthscale=1., variance=1., dtype='f64', device=None, optimize=True, max_iters=1000, ARD=False):
+        """``ARD=True``: one length-scale per input dimension (GPy's ``RBF(ARD=True)``, which the
+        reference's comparison script fits, scripts/tests/GPRBF_vs_ciMRGP_vs_fiMRGP.py:118; the plugin
+        itself is ``ARD=False``, RegressionInput.py:60).  Inputs are divided by their length-scales
+        and every kernel then runs with unit length-scale; ``self.lengthscales`` holds the vector.
+        ``optimize=True`` (default) is the reference's behaviour: its ``_fit`` always calls
         ``model.optimize()`` (RegressionInput.py:63).  ``optimize=False`` keeps the starting
         hyper-parameters (GPy's defaults l = 1, variance = 1, noise = 1 % of the label variance):
         the opt-in fast path, and the definition of the fixed-parameter parity target."""
         super(GP_RBF, self).__init__()
         self._initial = (float(lengthscale), float(variance))
+        self.ARD = bool(ARD)
+        self.lengthscales = None             # ARD: (d,) vector after fit
         self.kernel = RBFKernel(l=lengthscale, sf=variance)
         self.dtype = dev.as_torch_dtype(dtype)
         self.device = device
@@ -113,6 +119,47 @@ class GP_RBF(RegressionMethod):
         grad = dev.lml_grad(x, kinv, n, alpha, ell, sf, noise).cpu().numpy()
         return lml, grad
 
+    def log_marginal_likelihood_ard(self, x, y, ells, sf, noise):
+        """ARD twin of :meth:`log_marginal_likelihood`: ``ells`` (d,) length-scales; gradient w.r.t.
+        (log sf, log l_1 .. log l_d, log noise)."""
+        scale = torch.as_tensor(1.0 / np.asarray(ells, dtype=np.float64), dtype=x.dtype, device=x.device)
+        xs = (x * scale).contiguous()
+        n, q = y.shape
+        kbuf = dev.rbf_gram(xs, 1.0, sf, noise, lower_only=True)
+        ws, info = dev.potrf(kbuf, n)
+        alpha = y.clone()
+        dev.potrs(kbuf, n, ws, alpha)
+        dev.raise_if_not_pd(info)
+        half_logdet = float(dev.logdet_half(kbuf, n).item())
+        lml = -0.5 * float((y * alpha).sum().item()) - q * half_logdet - 0.5 * n * q * np.log(2 * np.pi)
+        u = dev.alloc_matrix(n, n, x.dtype, x.device)
+        u.zero_()
+        u[:n, :n].fill_diagonal_(1.0)
+        dev.trsm_rows(kbuf, n, ws, u, n)
+        kinv = dev.alloc_matrix(n, n, x.dtype, x.device)
+        kinv.zero_()
+        dev.syrk_lower(kinv, u, n, n)
+        kinv.neg_()
+        return lml, dev.lml_grad_ard(xs, kinv, n, alpha, sf, noise).cpu().numpy()
+
+    def _optimize_ard(self, x, y, noise0):
+        from scipy.optimize import minimize
+        d = x.shape[1]
+        theta0 = np.log([self.kernel.sf] + [self.kernel.l] * d + [noise0])
+
+        def objective(theta):
+            sf, ells, noise = np.exp(theta[0]), np.exp(theta[1:1 + d]), np.exp(theta[-1])
+            try:
+                lml, grad = self.log_marginal_likelihood_ard(x, y, ells, sf, noise)
+            except np.linalg.LinAlgError:
+                return 1e100, np.zeros(d + 2)
+            return -lml, -grad
+
+        res = minimize(objective, theta0, jac=True, method='L-BFGS-B', options=dict(maxiter=self.max_iters))
+        self.optimizer_result = res
+        self.lengthscales = np.exp(res.x[1:1 + d])
+        self.kernel = RBFKernel(l=1.0, sf=float(np.exp(res.x[0])), noise=float(np.exp(res.x[-1])))
+
     def _optimize(self, x, y, noise0):
         from scipy.optimize import minimize
         theta0 = np.log([self.kernel.sf, self.kernel.l, noise0])
@@ -141,7 +188,15 @@ class GP_RBF(RegressionMethod):
         self.kernel.noise = float(labels.var()) * NOISE_FRACTION
         x = dev.to_device(inputs, self.dtype, device)
         y = dev.to_device(labels, self.dtype, device)
-        if self.optimize:
+        if self.ARD:
+            if self.optimize:
+                self._optimize_ard(x, y, self.kernel.noise)
+            else:
+                self.lengthscales = np.full(x.shape[1], self.kernel.l)
+                self.kernel = RBFKernel(l=1.0, sf=self.kernel.sf, noise=self.kernel.noise)
+            self._scale = torch.as_tensor(1.0 / self.lengthscales, dtype=self.dtype, device=device)
+            x = (x * self._scale).contiguous()           # unit length-scale from here on
+        elif self.optimize:
             self._optimize(x, y, self.kernel.noise)
         self.block = DenseBlock(x, self.kernel)
         zero_bias = torch.zeros(y.shape[1], dtype=self.dtype, device=device)
@@ -156,6 +211,8 @@ class GP_RBF(RegressionMethod):
     def _predict_mean_var(self, test_data, want_var):
         blk = self.block
         xs = dev.to_device(np.atleast_2d(np.asarray(test_data, dtype=np.float64)), self.dtype, blk.x.device)
+        if self.ARD:
+            xs = (xs * self._scale).contiguous()
         q = blk.alpha.shape[1]
         mean = torch.zeros((xs.shape[0], q), dtype=self.dtype, device=xs.device)
         var = torch.zeros(xs.shape[0], dtype=self.dtype, device=xs.device) if want_var else None

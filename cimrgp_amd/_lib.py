@@ -40,6 +40,7 @@ SIGNATURES = {
     "cimrgp_syrk_lower": (_i32, [_i32, _vp, _i64, _vp, _i64, _i64, _i64, _vp]),
     "cimrgp_lml_grad_scratch_bytes": (_sz, [_i64]),
     "cimrgp_lml_grad": (_i32, [_i32, _vp, _i64, _i32, _vp, _i64, _vp, _i32, _dbl, _dbl, _dbl, _vp, _vp, _vp]),
+    "cimrgp_lml_grad_ard": (_i32, [_i32, _vp, _i64, _i32, _vp, _i64, _vp, _i32, _dbl, _dbl, _vp, _vp, _vp]),
     "cimrgp_laplace_basis": (_i32, [_i32, _vp, _i64, _i32, _vp, _i32, _vp, _vp]),
     "cimrgp_basis_moments_scratch_bytes": (_sz, [_i64, _i32, _i32]),
     "cimrgp_basis_moments": (_i32, [_i32, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),

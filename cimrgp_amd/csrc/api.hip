@@ -320,11 +320,25 @@ int cimrgp_lml_grad(int dtype, const void* x_dev, int64_t n, int d, const void* 
                                   sf2, noise, out_dev, scratch_dev, S(stream)));
 }
 
+int cimrgp_lml_grad_ard(int dtype, const void* xs_dev, int64_t n, int d, const void* kinv_dev, int64_t ldk,
+                        const void* alpha_dev, int q, double sf2, double noise, double* out_dev, double* scratch_dev,
+                        void* stream)
+{
+    const char* fn = "cimrgp_lml_grad_ard";
+    CIMRGP_REQUIRE(xs_dev && kinv_dev && alpha_dev && out_dev && scratch_dev, fn, "null pointer");
+    CIMRGP_REQUIRE(ldk >= n, fn, "bad dimensions");
+    DISPATCH(dtype, fn,
+             lml_grad_run<float>((const float*)xs_dev, n, d, (const float*)kinv_dev, ldk, (const float*)alpha_dev, q, 1.0, sf2,
+                                 noise, out_dev, scratch_dev, S(stream), true),
+             lml_grad_run<double>((const double*)xs_dev, n, d, (const double*)kinv_dev, ldk, (const double*)alpha_dev, q, 1.0,
+                                  sf2, noise, out_dev, scratch_dev, S(stream), true));
+}
+
 size_t cimrgp_lml_grad_scratch_bytes(int64_t n)
 {
     if (n <= 0) return 0;
     const int64_t tm = (n + 63) / 64;
-    return (size_t)(tm * (tm + 1) / 2) * 3 * sizeof(double);
+    return (size_t)(tm * (tm + 1) / 2) * 10 * sizeof(double);      // 10 = the ARD record (sf | 8 dimensions | trace)
 }
 
 int cimrgp_laplace_basis(int dtype, const void* x_dev, int64_t n, int d, const double* interval_dev, int m, void* phi_dev,

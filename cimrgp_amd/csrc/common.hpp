@@ -138,7 +138,8 @@ template <typename T> int misc_add_diag(T* k, int64_t n, int64_t ld, const T* no
 template <typename T> int misc_noise_from_stats(const T* stats, int q, double frac, double floor_value, T* noise, hipStream_t st);
 template <typename T> int misc_logdet_half(const T* l, int64_t n, int64_t ld, double* out, hipStream_t st);
 template <typename T> int lml_grad_run(const T* x, int64_t n, int d, const T* kinv, int64_t ld, const T* alpha, int q,
-                                       double ell, double sf2, double noise, double* out3, double* scratch, hipStream_t st);
+                                       double ell, double sf2, double noise, double* out3, double* scratch, hipStream_t st,
+                                       bool ard = false);
 
 // reduced.hip
 template <typename T> int laplace_basis_run(const T* x, int64_t n, int d, const double* interval, int m, T* phi, hipStream_t st);

@@ -195,7 +195,12 @@ namespace {
 constexpr int LG_T = 64;
 constexpr int LG_MAXD = 8;
 
-template <typename T>
+// ARD: one length-scale per input dimension.  The caller passes inputs already divided by their
+// length-scales (so the kernel is evaluated with l = 1) and gets d/dlog l_k = 1/2 sum G K d_k^2 per
+// dimension: partial record = [sf | l_1 .. l_8 | trace] (LG_NP entries) instead of [sf | l | trace].
+constexpr int LG_NP = LG_MAXD + 2;
+
+template <typename T, bool ARD>
 __global__ __launch_bounds__(256)
 void k_lml_grad_tiles(const T* __restrict__ x, int n, int d, const T* __restrict__ kinv, int64_t ld,
                       const T* __restrict__ alpha, int q, T neg_half_inv_l2, T sf2, T inv_l2,
@@ -203,7 +208,7 @@ void k_lml_grad_tiles(const T* __restrict__ x, int n, int d, const T* __restrict
 {
     __shared__ T sa[LG_T * LG_MAXD], sb[LG_T * LG_MAXD];
     __shared__ T aa[LG_T * 8], ab[LG_T * 8];
-    __shared__ double red[3][4];
+    __shared__ double red[ARD ? LG_NP : 3][4];
     const int id = blockIdx.x;
     int ti = (int)((sqrtf(8.0f * (float)id + 1.0f) - 1.0f) * 0.5f);
     while (ti * (ti + 1) / 2 > id) --ti;
@@ -221,15 +226,20 @@ void k_lml_grad_tiles(const T* __restrict__ x, int n, int d, const T* __restrict
     __syncthreads();
     const int tx = tid & 63, ty = tid >> 6;
     double s_sf = 0.0, s_l = 0.0, s_tr = 0.0;
+    double s_lk[ARD ? LG_MAXD : 1];
+#pragma unroll
+    for (int k = 0; k < (ARD ? LG_MAXD : 1); ++k) s_lk[k] = 0.0;
     const int gc = col0 + tx;
     for (int rr = ty; rr < LG_T; rr += 4) {
         const int gr = row0 + rr;
         if (gr < n && gc < n && gc <= gr) {
             T d2 = (T)0;
+            T dk2[LG_MAXD];
 #pragma unroll
             for (int k = 0; k < LG_MAXD; ++k) {
                 const T df = sa[rr * LG_MAXD + k] - sb[tx * LG_MAXD + k];
-                d2 += df * df;
+                dk2[k] = df * df;
+                d2 += dk2[k];
             }
             T aat = (T)0;
 #pragma unroll
@@ -238,7 +248,12 @@ void k_lml_grad_tiles(const T* __restrict__ x, int n, int d, const T* __restrict
             const T kf = sf2 * exp(d2 * neg_half_inv_l2);
             const double wgt = (gr == gc) ? 1.0 : 2.0;
             s_sf += wgt * (double)(g * kf);
-            s_l  += wgt * (double)(g * kf * d2 * inv_l2);
+            if (ARD) {
+#pragma unroll
+                for (int k = 0; k < LG_MAXD; ++k) s_lk[k] += wgt * (double)(g * kf * dk2[k]);
+            } else {
+                s_l  += wgt * (double)(g * kf * d2 * inv_l2);
+            }
             if (gr == gc) s_tr += (double)g;
         }
     }
@@ -247,21 +262,40 @@ void k_lml_grad_tiles(const T* __restrict__ x, int n, int d, const T* __restrict
         s_sf += __shfl_xor(s_sf, off, 64);
         s_l  += __shfl_xor(s_l, off, 64);
         s_tr += __shfl_xor(s_tr, off, 64);
+        if (ARD) {
+#pragma unroll
+            for (int k = 0; k < LG_MAXD; ++k) s_lk[k] += __shfl_xor(s_lk[k], off, 64);
+        }
     }
-    if (tx == 0) { red[0][ty] = s_sf; red[1][ty] = s_l; red[2][ty] = s_tr; }
-    __syncthreads();
-    if (tid < 3) partial[(int64_t)id * 3 + tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+    if (ARD) {
+        if (tx == 0) {
+            red[0][ty] = s_sf;
+#pragma unroll
+            for (int k = 0; k < LG_MAXD; ++k) red[1 + k][ty] = s_lk[k];
+            red[LG_NP - 1][ty] = s_tr;
+        }
+        __syncthreads();
+        if (tid < LG_NP) partial[(int64_t)id * LG_NP + tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+    } else {
+        if (tx == 0) { red[0][ty] = s_sf; red[1][ty] = s_l; red[2][ty] = s_tr; }
+        __syncthreads();
+        if (tid < 3) partial[(int64_t)id * 3 + tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+    }
 }
 
 __global__ __launch_bounds__(1024)
-void k_lml_grad_final(const double* __restrict__ partial, int64_t ntiles, double noise, double* __restrict__ out)
+void k_lml_grad_final(const double* __restrict__ partial, int64_t ntiles, double noise, double* __restrict__ out,
+                      int np, int nout)
 {
+    // np entries per tile record, the last one the trace term; the first nout - 1 are copied out
     __shared__ double red[16];
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < nout; ++c) {
+        const int src = (c == nout - 1) ? np - 1 : c;
         double s = 0.0;
-        for (int64_t t = threadIdx.x; t < ntiles; t += blockDim.x) s += partial[t * 3 + c];
+        for (int64_t t = threadIdx.x; t < ntiles; t += blockDim.x) s += partial[t * np + src];
         s = block_sum_1024(s, red);
-        if (threadIdx.x == 0) out[c] = 0.5 * s * (c == 2 ? noise : 1.0);
+        if (threadIdx.x == 0) out[c] = 0.5 * s * (c == nout - 1 ? noise : 1.0);
+        __syncthreads();
     }
 }
 
@@ -269,7 +303,7 @@ void k_lml_grad_final(const double* __restrict__ partial, int64_t ntiles, double
 
 template <typename T>
 int lml_grad_run(const T* x, int64_t n, int d, const T* kinv, int64_t ld, const T* alpha, int q,
-                 double ell, double sf2, double noise, double* out3, double* scratch, hipStream_t st)
+                 double ell, double sf2, double noise, double* out3, double* scratch, hipStream_t st, bool ard)
 {
     const char* fn = "cimrgp_lml_grad";
     CIMRGP_REQUIRE(n > 0 && n < (1ll << 30), fn, "bad size");
@@ -277,17 +311,25 @@ int lml_grad_run(const T* x, int64_t n, int d, const T* kinv, int64_t ld, const 
     CIMRGP_REQUIRE(q >= 1 && q <= 8, fn, "number of outputs must be in [1, 8]");
     const int64_t tm = (n + LG_T - 1) / LG_T, tiles = tm * (tm + 1) / 2;
     CIMRGP_REQUIRE(tiles < (1ll << 31), fn, "grid too large");
-    hipLaunchKernelGGL((k_lml_grad_tiles<T>), dim3((unsigned)tiles), dim3(256), 0, st, x, (int)n, d, kinv, ld, alpha, q,
-                       (T)(-0.5 / (ell * ell)), (T)sf2, (T)(1.0 / (ell * ell)), scratch);
-    CIMRGP_LAUNCH_CHECK(fn);
-    hipLaunchKernelGGL(k_lml_grad_final, dim3(1), dim3(1024), 0, st, (const double*)scratch, tiles, noise, out3);
+    if (ard) {
+        // inputs are pre-scaled by the length-scales: unit length-scale here; out = [sf | l_1..l_d | noise]
+        hipLaunchKernelGGL((k_lml_grad_tiles<T, true>), dim3((unsigned)tiles), dim3(256), 0, st, x, (int)n, d, kinv, ld, alpha, q,
+                           (T)(-0.5), (T)sf2, (T)1, scratch);
+        CIMRGP_LAUNCH_CHECK(fn);
+        hipLaunchKernelGGL(k_lml_grad_final, dim3(1), dim3(1024), 0, st, (const double*)scratch, tiles, noise, out3, LG_NP, d + 2);
+    } else {
+        hipLaunchKernelGGL((k_lml_grad_tiles<T, false>), dim3((unsigned)tiles), dim3(256), 0, st, x, (int)n, d, kinv, ld, alpha, q,
+                           (T)(-0.5 / (ell * ell)), (T)sf2, (T)(1.0 / (ell * ell)), scratch);
+        CIMRGP_LAUNCH_CHECK(fn);
+        hipLaunchKernelGGL(k_lml_grad_final, dim3(1), dim3(1024), 0, st, (const double*)scratch, tiles, noise, out3, 3, 3);
+    }
     CIMRGP_LAUNCH_CHECK(fn);
     return 0;
 }
 
 template int lml_grad_run<double>(const double*, int64_t, int, const double*, int64_t, const double*, int, double, double,
-                                  double, double*, double*, hipStream_t);
+                                  double, double*, double*, hipStream_t, bool);
 template int lml_grad_run<float>(const float*, int64_t, int, const float*, int64_t, const float*, int, double, double,
-                                 double, double*, double*, hipStream_t);
+                                 double, double*, double*, hipStream_t, bool);
 
 }  // namespace cimrgp

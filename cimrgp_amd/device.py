@@ -276,6 +276,18 @@ def lml_grad(x, kinv, n, alpha, ell, sf2, noise):
     return out
 
 
+def lml_grad_ard(x_scaled, kinv, n, alpha, sf2, noise):
+    """ARD gradient w.r.t. (log sf, log l_1..l_d, log noise); ``x_scaled`` = inputs / length-scales."""
+    lib = _lib.load()
+    d = x_scaled.shape[1]
+    out = torch.empty(d + 2, dtype=torch.float64, device=x_scaled.device)
+    scratch = torch.empty(max(lib.cimrgp_lml_grad_scratch_bytes(int(n)), 8) // 8, dtype=torch.float64, device=x_scaled.device)
+    _lib.check(lib.cimrgp_lml_grad_ard(_DT[x_scaled.dtype], _p(x_scaled), int(n), d, _p(kinv), kinv.stride(0), _p(alpha),
+                                       alpha.shape[1], float(sf2), float(noise), _p(out), _p(scratch), _stream()),
+               "cimrgp_lml_grad_ard")
+    return out
+
+
 # ---- reduced-rank (Laplacian basis) block path ------------------------------------------------
 def _f64dev(a, device):
     return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(device)

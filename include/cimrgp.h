@@ -197,6 +197,16 @@ int cimrgp_lml_grad(int dtype, const void* x_dev, int64_t n, int d,
                     double ell, double sf2, double noise, double* out_dev,
                     double* scratch_dev, void* stream);
 
+/* The same for one length-scale PER INPUT DIMENSION (GPy's RBF(ARD=True), the reference's
+ * comparison script scripts/tests/GPRBF_vs_ciMRGP_vs_fiMRGP.py:118).  xs_dev holds the inputs
+ * already divided by their length-scales (the kernel of scaled inputs has unit length-scale, so
+ * every other entry point serves ARD unchanged);  out_dev[0] = d/dlog sf, out_dev[1..d] = d/dlog l_k,
+ * out_dev[d+1] = d/dlog noise  (d + 2 doubles). */
+int cimrgp_lml_grad_ard(int dtype, const void* xs_dev, int64_t n, int d,
+                        const void* kinv_dev, int64_t ldk, const void* alpha_dev, int q,
+                        double sf2, double noise, double* out_dev,
+                        double* scratch_dev, void* stream);
+
 /* ---- reduced-rank (Laplacian basis) block path of the reference, SURVEY.md 8f rank 2 ----
  * Phi (n x m row-major, ld = m):  phi_i(x) = prod_k L_k^-1/2 sin(pi i (x_k + L_k)/(2 L_k)),
  * i = 1..m  (KernelClass.py:22-37, assembled as in MRGP.py:337-357).  interval_dev: d doubles. */

@@ -25,7 +25,8 @@ from .structure import (index_bounds_uniform, index_set_from_bounds,
                         concat_regions, latent_from_coarser, sum_over_layers)
 from .dense import (rbf_gram, block_fit, block_predict, potrf_lower)
 from .mrgp import (DenseLayerSpec, mrgp_fit, mrgp_predict, gp_rbf_fit,
-                   gp_rbf_predict, gp_lml_and_grad, gp_rbf_optimize)
+                   gp_rbf_predict, gp_lml_and_grad, gp_rbf_optimize,
+                   gp_lml_and_grad_ard, gp_rbf_optimize_ard, gp_rbf_predict_ard)
 
 __all__ = [
     "index_bounds_uniform", "index_set_from_bounds", "normalize_inputs",
@@ -33,4 +34,5 @@ __all__ = [
     "sum_over_layers", "rbf_gram", "block_fit", "block_predict",
     "potrf_lower", "DenseLayerSpec", "mrgp_fit", "mrgp_predict", "gp_rbf_fit",
     "gp_rbf_predict", "gp_lml_and_grad", "gp_rbf_optimize",
+    "gp_lml_and_grad_ard", "gp_rbf_optimize_ard", "gp_rbf_predict_ard",
 ]

@@ -178,3 +178,53 @@ def gp_rbf_optimize(inputs, labels, max_iters=1000):
     sf2, ell, noise = np.exp(res.x)
     fit = block_fit(xz, yz, ell, sf2, noise)
     return dict(stats=stats, xz=xz, fit=fit, ell=ell, sf2=sf2, noise=noise, result=res)
+
+
+def gp_lml_and_grad_ard(x, y, ells, sf2, noise):
+    """ARD twin of :func:`gp_lml_and_grad` (GPy ``RBF(ARD=True)``, the reference's comparison
+    script scripts/tests/GPRBF_vs_ciMRGP_vs_fiMRGP.py:118): one length-scale per input dimension;
+    gradient w.r.t. (log sf2, log l_1 .. log l_d, log noise)."""
+    import scipy.linalg as sla
+    from .dense import rbf_gram
+    ells = np.asarray(ells, dtype=np.float64)
+    n, q = y.shape
+    xs = x / ells
+    kf = rbf_gram(xs, None, 1.0, sf2, 0.0)
+    chol = sla.cholesky(kf + noise * np.eye(n), lower=True)
+    alpha = sla.cho_solve((chol, True), y)
+    lml = -0.5 * np.sum(y * alpha) - q * np.sum(np.log(np.diag(chol))) - 0.5 * n * q * np.log(2 * np.pi)
+    g = alpha @ alpha.T - q * sla.cho_solve((chol, True), np.eye(n))
+    grad = [0.5 * np.sum(g * kf)]
+    for k in range(x.shape[1]):
+        dk = xs[:, k][:, None] - xs[:, k][None, :]
+        grad.append(0.5 * np.sum(g * kf * dk * dk))
+    grad.append(0.5 * noise * np.trace(g))
+    return lml, np.array(grad)
+
+
+def gp_rbf_optimize_ard(inputs, labels, max_iters=1000):
+    """``GPRegression(RBF(ARD=True))`` + ``optimize()`` on z-scored data, L-BFGS-B from GPy's defaults."""
+    from scipy.optimize import minimize
+    stats = zscore_fit(inputs, labels)
+    xz, yz = zscore_apply(stats, inputs=inputs, labels=labels)
+    d = xz.shape[1]
+    theta0 = np.log([1.0] + [1.0] * d + [float(yz.var()) * NOISE_FRACTION])
+
+    def objective(theta):
+        try:
+            lml, grad = gp_lml_and_grad_ard(xz, yz, np.exp(theta[1:1 + d]), np.exp(theta[0]), np.exp(theta[-1]))
+        except np.linalg.LinAlgError:
+            return 1e100, np.zeros(d + 2)
+        return -lml, -grad
+
+    res = minimize(objective, theta0, jac=True, method='L-BFGS-B', options=dict(maxiter=max_iters))
+    sf2, ells, noise = np.exp(res.x[0]), np.exp(res.x[1:1 + d]), np.exp(res.x[-1])
+    fit = block_fit(xz / ells, yz, 1.0, sf2, noise)
+    return dict(stats=stats, xz=xz / ells, fit=fit, ell=1.0, ells=ells, sf2=sf2, noise=noise, result=res)
+
+
+def gp_rbf_predict_ard(state, test_inputs, want_var=False):
+    xs = zscore_apply(state['stats'], inputs=test_inputs) / state['ells']
+    mean, var = block_predict(state['xz'], state['fit'], xs, 1.0, state['sf2'], want_var)
+    mean = zscore_apply(state['stats'], inverse_labels=mean)
+    return (mean, var) if want_var else mean

@@ -316,3 +316,40 @@ def test_adaptive_inputs_warp(ca):
     omean, _ = oracle.mrgp_predict(z, omodel, specs, model.input_obj.warp((xs - mu) / sd),
                                    oracle.index_bounds_uniform(ns, res, 2), want_var=False)
     assert _relerr(mean, omean) < 1e-6
+
+
+def test_ard_lml_gradient_and_optimised_fit(ca):
+    """``GP_RBF(ARD=True)``: one length-scale per input dimension, as the reference's comparison
+    script fits with GPy (scripts/tests/GPRBF_vs_ciMRGP_vs_fiMRGP.py:118).  LML and its d + 2
+    gradient entries against the oracle; the optimised fit and its predictions against the oracle's
+    L-BFGS-B optimum."""
+    rng = np.random.default_rng(31)
+    n = 220
+    x = rng.uniform(-2, 2, size=(n, 3))
+    # the second input matters little, the third not at all: ARD must give it a long length-scale
+    y = np.stack([np.sin(2.5 * x[:, 0]) + 0.2 * x[:, 1], np.cos(1.5 * x[:, 0]) * (1 + 0.1 * x[:, 1])], axis=1)
+    y += 0.05 * rng.normal(size=y.shape)
+    xt = rng.uniform(-1.8, 1.8, size=(50, 3))
+    model = ca.GP_RBF(ARD=True)
+    xd = ca.device.to_device(x, torch.float64, "cuda")
+    yd = ca.device.to_device(y, torch.float64, "cuda")
+    for ells, sf, noise in [((1.0, 1.0, 1.0), 1.0, 0.01), ((0.5, 1.7, 3.0), 1.4, 0.1)]:
+        lml, grad = model.log_marginal_likelihood_ard(xd, yd, ells, sf, noise)
+        olml, ograd = oracle.gp_lml_and_grad_ard(x, y, ells, sf, noise)
+        assert grad.shape == (5,)
+        assert abs(lml - olml) < 1e-8 * abs(olml)
+        np.testing.assert_allclose(grad, ograd, rtol=1e-7, atol=1e-7 * np.max(np.abs(ograd)))
+    assert model.fit([x, y]) is True
+    ref = oracle.gp_rbf_optimize_ard(x, y)
+    assert model.optimizer_result.success
+    np.testing.assert_allclose(model.lengthscales[0], ref["ells"][0], rtol=2e-3)
+    assert model.lengthscales[2] > 5 * model.lengthscales[0]            # the irrelevant input is switched off
+    pred = model.predict(xt)
+    opred = oracle.gp_rbf_predict_ard(ref, xt)
+    assert _relerr(pred, opred) < 1e-3
+    # isotropic start without optimisation = the plain kernel
+    fixed_ard = ca.GP_RBF(ARD=True, optimize=False)
+    fixed_iso = ca.GP_RBF(optimize=False)
+    fixed_ard.fit([x, y])
+    fixed_iso.fit([x, y])
+    assert _relerr(fixed_ard.predict(xt), fixed_iso.predict(xt)) < 1e-12
