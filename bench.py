@@ -136,7 +136,11 @@ def main():
         # cuda:0, gloo carrying the device tensors); the driver's multi-GPU runs use nccl = RCCL
         rehearsal = os.environ.get("CIMRGP_BENCH_REHEARSAL", "")
         torch.cuda.set_device(0 if rehearsal else local_rank)
-        td.init_process_group(rehearsal or "nccl", rank=rank, world_size=world)
+        if rehearsal:
+            td.init_process_group(rehearsal, rank=rank, world_size=world)
+        else:
+            # device_id: the communicator is bound to this rank's GPU up front (no guessing in barrier())
+            td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     device = dev.require_gpu()

@@ -302,3 +302,26 @@ def test_config5_n16384_fp64_and_fp32_against_oracle(ca):
     assert i32_bad > 0
     i64_ok, _, _ = _posterior(dev, x, y, xs, ell, sf2, 1e-4, torch.float64)
     assert i64_ok == 0
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """``python bench.py --gpus 2`` with WORLD_SIZE unset starts two ranks itself (before any GPU
+    call in the parent) and rank 0 prints ONE JSON line with n_gpus == 2.  On this one-GPU box the
+    ranks share the card and gloo carries the reduce (CIMRGP_BENCH_REHEARSAL); the driver's
+    multi-GPU runs use nccl = RCCL with one GPU per rank."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["CIMRGP_BENCH_REHEARSAL"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--n", "2048"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "weak" and rec["unit"] == "posteriors/s"
+    assert rec["value"] > 0 and "roofline" in rec and "cpu_baseline" not in rec
