@@ -92,18 +92,36 @@ def cpu_baseline(n, ns, q, ell, sf2, noise, seed, warmups=3, repeats=5):
 
 
 def launch_ranks(args):
-    """``python bench.py --gpus N`` without a launcher: start N ranks as children of
-    ``torch.distributed.run`` BEFORE this process has made any GPU call (it never makes one), hand
-    them the same flags, pass their output through and exit with their status."""
+    """``python bench.py --gpus N`` without a launcher: start N ranks of this script as child
+    processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, one GPU each) BEFORE
+    this process has made any GPU call (it never makes one), let them print, and exit with their
+    status.  Children are started directly rather than through ``torch.distributed.run``: its
+    argument parser tries to abbreviate-match this script's own flags (``--n``)."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "8")
-    return subprocess.call(cmd, env=env)
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "8")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            time.sleep(0.2)
+            failed = [p.returncode for p in procs if p.poll() not in (None, 0)]
+            if failed:                       # a rank that failed must not leave the others waiting in a collective
+                rc = abs(failed[0])
+                break
+        rc = max([rc] + [abs(p.returncode) for p in procs if p.poll() is not None])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 def main():
