@@ -316,6 +316,18 @@ void k_diag64(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow, 
     __builtin_amdgcn_s_setprio(3);
 
     STAMP(0);
+    // the block's own elements are requested first (they depend on nothing), so that their round
+    // trip overlaps the left-looking update below instead of following it
+    T dval[2][4];
+    if (tile_wave) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = br * 16 + X::crow(lane, r), col = (2 * ch + c) * 16 + fcol;
+                dval[c][r] = (row < w && col <= row) ? D[(int64_t)row * ld + col] : (T)0;
+            }
+    }
     // S = A_ss - Lrow Lrow^T, straight into the accumulator layout
     acc_t pacc[2];
     pacc[0] = acc_zero<T>();
@@ -366,7 +378,7 @@ void k_diag64(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow, 
             for (int r = 0; r < 4; ++r) {
                 const int row = br * 16 + X::crow(lane, r), col = (2 * ch + c) * 16 + fcol;
                 T v = (row == col) ? (T)1 : (T)0;                   // identity padding; strict upper part is zero
-                if (row < w && col <= row) v = D[(int64_t)row * ld + col] - pacc[c][r];
+                if (row < w && col <= row) v = dval[c][r] - pacc[c][r];
                 acc[c][r] = v;
             }
         // blocks 0 and 1 for the pivot wave (both in tile column 0)
@@ -513,6 +525,14 @@ static __device__ __forceinline__ void trsm64_body(T* __restrict__ Prow, int64_t
 
     STAMP(8);
     uint4 ra[TR * TL::CPR / 256], rb[SB * TL::CPR / 256];
+    // the inverted diagonal block is needed last but depends on nothing: requested first, parked in
+    // registers, so that its round trip hides behind the whole K loop instead of following it
+    uint4 rinv[SB * TL::CPR / 256];
+#pragma unroll
+    for (int p = 0; p < SB * TL::CPR / 256; ++p) {
+        const int e = tid + 256 * p, r = e / TL::CPR, c = e - r * TL::CPR;
+        rinv[p] = *reinterpret_cast<const uint4*>(invL + r * SB + c * X::EPC);
+    }
     if (kprev > 0) {
         gload_tile64<T, TR>(ra, Pprev, ldp, mrows, SB);
         gload_tile64<T, SB>(rb, Lrow, ldl, kw, SB);
@@ -544,11 +564,7 @@ static __device__ __forceinline__ void trsm64_body(T* __restrict__ Prow, int64_t
                 *t -= acc[c][r];
             }
     }
-    for (int e = tid; e < SB * TL::CPR; e += 256) {
-        const int r = e / TL::CPR, c = e - r * TL::CPR;
-        *reinterpret_cast<uint4*>(bs + r * TL::LROW + c * 16) =
-            *reinterpret_cast<const uint4*>(invL + r * SB + c * X::EPC);
-    }
+    swrite_tile64<T, SB>(bs, rinv);
     __syncthreads();
     acc[0] = acc_zero<T>(); acc[1] = acc_zero<T>();
     STAMP(10);
