@@ -9,6 +9,7 @@
 // Right-hand sides are kept "RHS-major" (q x n) so the updates are coalesced.
 // HBM-read bound: n^2/2 * sizeof(T) bytes per direction.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace cimrgp {
 
@@ -236,6 +237,106 @@ void k_bwd_panel(const T* __restrict__ L, int64_t ld, int n, const T* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------
+// Backward panel step in two narrow-latency launches (round 2): the redundant inverse apply of
+// k_bwd_panel streams 512 KB of invT through EVERY workgroup before its update can start.
+//   k_bwd_alpha   a_p = invT_p w_p : one wave per row of invT_p (upper triangular: columns >= row),
+//                 2 KB per row, 64 workgroups of 4 rows;
+//   k_bwd_update  w[cols left of the panel] -= L[panel, cols]^T a_p : thread = column, 16-way split
+//                 over the panel's rows, 64 columns per workgroup; a_p (w x Q) read once per workgroup.
+// Both keep a fixed summation order (bit-identical on repetition).
+// ---------------------------------------------------------------------------
+template <typename T, int Q>
+__global__ __launch_bounds__(256)
+void k_bwd_alpha(const T* __restrict__ invT, int n, const T* __restrict__ work, T* __restrict__ out, int k0, int w,
+                 int64_t sws = 0, int64_t sscr = 0)
+{
+    invT += (int64_t)blockIdx.y * sws;
+    work += (int64_t)blockIdx.y * sscr;
+    out += (int64_t)blockIdx.y * sscr;
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= w) return;
+    const T* rp = invT + (int64_t)(k0 / PW) * (PW * PW) + (int64_t)r * PW + lane * 4;
+    T bv[4], wv[Q][4];
+    const bool live = lane * 4 + 3 >= r;             // this lane's columns reach the diagonal or beyond
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[e] = live ? rp[e] : (T)0;
+#pragma unroll
+    for (int c = 0; c < Q; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int u = lane * 4 + e;
+            wv[c][e] = (live && u < w) ? work[(int64_t)c * n + k0 + u] : (T)0;
+        }
+#pragma unroll
+    for (int c = 0; c < Q; ++c) {
+        T sv = bv[0] * wv[c][0];
+#pragma unroll
+        for (int e = 1; e < 4; ++e) sv += bv[e] * wv[c][e];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sv += __shfl_xor(sv, off, 64);
+        if (lane == 0) out[(int64_t)c * n + k0 + r] = sv;
+    }
+}
+
+template <typename T, int Q>
+__global__ __launch_bounds__(ST)
+void k_bwd_update(const T* __restrict__ L, int64_t ld, int n, T* __restrict__ work, const T* __restrict__ alpha,
+                  int k0, int w, int64_t sk = 0, int64_t sscr = 0)
+{
+    L += (int64_t)blockIdx.y * sk;
+    work += (int64_t)blockIdx.y * sscr;
+    alpha += (int64_t)blockIdx.y * sscr;
+    __shared__ T zs[Q][PW];
+    __shared__ T red[16][Q][SB];
+    const int tid = threadIdx.x;
+    const int t = tid & 63, part = tid >> 6;                      // 16 row parts of 16
+    const int col = blockIdx.x * SB + t;
+    const int ubeg = part * 16;
+    T lv[16];
+    if (col < k0) {
+        const T* lp = L + (int64_t)k0 * ld + col;
+        if (w == PW) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) lv[e] = lp[(int64_t)(ubeg + e) * ld];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) lv[e] = (ubeg + e < w) ? lp[(int64_t)(ubeg + e) * ld] : (T)0;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) lv[e] = (T)0;
+    }
+    for (int e = tid; e < Q * PW; e += ST) {
+        const int c = e / PW, u = e - c * PW;
+        zs[c][u] = (u < w) ? alpha[(int64_t)c * n + k0 + u] : (T)0;
+    }
+    __syncthreads();
+    T acc[Q];
+#pragma unroll
+    for (int c = 0; c < Q; ++c) acc[c] = (T)0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+#pragma unroll
+        for (int c = 0; c < Q; ++c)
+            acc[c] += lv[e] * zs[c][ubeg + e];
+    }
+#pragma unroll
+    for (int c = 0; c < Q; ++c)
+        red[part][c][t] = acc[c];
+    __syncthreads();
+    if (part == 0 && col < k0) {
+#pragma unroll
+        for (int c = 0; c < Q; ++c) {
+            T sv = (T)0;
+#pragma unroll
+            for (int pp = 0; pp < 16; ++pp) sv += red[pp][c][t];
+            work[(int64_t)c * n + col] -= sv;
+        }
+    }
+}
+
 // D5 tail: one wave per row of W.
 template <typename T, int Q>
 __global__ __launch_bounds__(256)
@@ -334,12 +435,24 @@ int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* 
         if (e != hipSuccess) return check_hip(e, fn, "hipMemcpyAsync");
     }   // backward_only: `work` already holds z (RHS-major), put there by the first transpose
     const int64_t last = ((n - 1) / PW) * PW;
+    static const bool fused_bwd = (getenv("CIMRGP_BWD_FUSED") != nullptr);    // A/B switch: round 1's one-launch panel step
     for (int64_t k0 = last; k0 >= 0; k0 -= PW) {
         const int w = (int)((n - k0 < PW) ? (n - k0) : PW);
         const unsigned grid = (unsigned)((k0 + SB - 1) / SB);
-        CIMRGP_Q_SWITCH(q, hipLaunchKernelGGL((k_bwd_panel<T, QQ>), dim3(grid ? grid : 1, nbatch), dim3(ST), 0, st, l, ld, (int)n,
-                                              invT, work, res, q, (int)k0, w, bt.sk, bt.sws, sscr));
+        if (fused_bwd) {
+            CIMRGP_Q_SWITCH(q, hipLaunchKernelGGL((k_bwd_panel<T, QQ>), dim3(grid ? grid : 1, nbatch), dim3(ST), 0, st, l, ld, (int)n,
+                                                  invT, work, res, q, (int)k0, w, bt.sk, bt.sws, sscr));
+            CIMRGP_LAUNCH_CHECK(fn);
+            continue;
+        }
+        CIMRGP_Q_SWITCH(q, hipLaunchKernelGGL((k_bwd_alpha<T, QQ>), dim3((unsigned)((w + 3) / 4), nbatch), dim3(256), 0, st,
+                                              invT, (int)n, (const T*)work, res, (int)k0, w, bt.sws, sscr));
         CIMRGP_LAUNCH_CHECK(fn);
+        if (grid) {
+            CIMRGP_Q_SWITCH(q, hipLaunchKernelGGL((k_bwd_update<T, QQ>), dim3(grid, nbatch), dim3(ST), 0, st, l, ld, (int)n,
+                                                  work, (const T*)res, (int)k0, w, bt.sk, sscr));
+            CIMRGP_LAUNCH_CHECK(fn);
+        }
     }
     hipLaunchKernelGGL((k_transpose_nq<T>), dim3(tg, nbatch), dim3(256), 0, st, (const T*)res, rhs, n, q, 0, sscr, srhs);
     CIMRGP_LAUNCH_CHECK(fn);
