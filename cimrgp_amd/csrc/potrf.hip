@@ -84,6 +84,11 @@ constexpr int64_t ROWS_PAIR_ABOVE_SOLVE = 1024;   // stand-alone row-wise solve:
 constexpr int64_t ROWS_START_BELOW = 4608;   // carried rows start once the trailing matrix is smaller than this
 
 
+// 16 bytes in flight between global memory and LDS.  A first-class vector: arrays of HIP's uint4
+// struct filled from global memory stay in scratch (the optimiser does not split the struct copy).
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ v4u v4u_zero() { v4u z = {0u, 0u, 0u, 0u}; return z; }
+
 template <typename T> struct Tile64 {
     static constexpr int ROWB  = SB * (int)sizeof(T);   // bytes of 64 k-values per row
     static constexpr int LROW  = ROWB + 16;              // padded LDS row stride
@@ -92,6 +97,14 @@ template <typename T> struct Tile64 {
     static constexpr int KPS   = 32 / (int)sizeof(T);    // k values per slot-step
     static constexpr int BYTES = SB * LROW;
 };
+
+// mask_chunk for the first-class vector: zero the elements whose k index is >= kvalid
+template <typename T> static __device__ __forceinline__ v4u mask_v4u(v4u v, int kfirst, int kvalid)
+{
+    const uint4 m = mask_chunk<T>(make_uint4(v.x, v.y, v.z, v.w), kfirst, kvalid);
+    v4u o = {m.x, m.y, m.z, m.w};
+    return o;
+}
 
 // Cooperative, coalesced load of a 64 x kw strip (row stride ld elements) into a
 // padded LDS tile; rows >= mrows and columns >= kw are zero-filled.
@@ -104,19 +117,19 @@ static __device__ __forceinline__ void load_tile64(unsigned char* dst, const T* 
     for (int e = threadIdx.x; e < ROWS * TL::CPR; e += 256) {
         const int r = e / TL::CPR, c = e - r * TL::CPR;
         const int kcol = c * X::EPC;
-        uint4 v = make_uint4(0, 0, 0, 0);
+        v4u v = v4u_zero();
         if (r < mrows && kcol < kw) {
-            v = *reinterpret_cast<const uint4*>(src + (int64_t)r * ld + kcol);
-            if (kcol + X::EPC > kw) v = mask_chunk<T>(v, kcol, kw);
+            v = *reinterpret_cast<const v4u*>(src + (int64_t)r * ld + kcol);
+            if (kcol + X::EPC > kw) v = mask_v4u<T>(v, kcol, kw);
         }
-        *reinterpret_cast<uint4*>(dst + r * TL::LROW + c * 16) = v;
+        *reinterpret_cast<v4u*>(dst + r * TL::LROW + c * 16) = v;
     }
 }
 
 // Same strip, split in two halves so the global loads of the next k chunk can be in
 // flight (in registers) while the current chunk is multiplied.
 template <typename T, int ROWS>
-static __device__ __forceinline__ void gload_tile64(uint4 (&regs)[ROWS * Tile64<T>::CPR / 256], const T* __restrict__ src,
+static __device__ __forceinline__ void gload_tile64(v4u (&regs)[ROWS * Tile64<T>::CPR / 256], const T* __restrict__ src,
                                                      int64_t ld, int mrows, int kw)
 {
     using X = Mx<T>;
@@ -126,24 +139,24 @@ static __device__ __forceinline__ void gload_tile64(uint4 (&regs)[ROWS * Tile64<
         const int e = threadIdx.x + 256 * p;
         const int r = e / TL::CPR, c = e - r * TL::CPR;
         const int kcol = c * X::EPC;
-        uint4 v = make_uint4(0, 0, 0, 0);
+        v4u v = v4u_zero();
         if (r < mrows && kcol < kw) {
-            v = *reinterpret_cast<const uint4*>(src + (int64_t)r * ld + kcol);
-            if (kcol + X::EPC > kw) v = mask_chunk<T>(v, kcol, kw);
+            v = *reinterpret_cast<const v4u*>(src + (int64_t)r * ld + kcol);
+            if (kcol + X::EPC > kw) v = mask_v4u<T>(v, kcol, kw);
         }
         regs[p] = v;
     }
 }
 
 template <typename T, int ROWS>
-static __device__ __forceinline__ void swrite_tile64(unsigned char* dst, const uint4 (&regs)[ROWS * Tile64<T>::CPR / 256])
+static __device__ __forceinline__ void swrite_tile64(unsigned char* dst, const v4u (&regs)[ROWS * Tile64<T>::CPR / 256])
 {
     using TL = Tile64<T>;
 #pragma unroll
     for (int p = 0; p < ROWS * TL::CPR / 256; ++p) {
         const int e = threadIdx.x + 256 * p;
         const int r = e / TL::CPR, c = e - r * TL::CPR;
-        *reinterpret_cast<uint4*>(dst + r * TL::LROW + c * 16) = regs[p];
+        *reinterpret_cast<v4u*>(dst + r * TL::LROW + c * 16) = regs[p];
     }
 }
 
@@ -283,6 +296,147 @@ static __device__ __forceinline__ Mx<float>::acc_t mfma_k4(float a, float b, Mx<
 // (Version 1 kept A in "lane = row" registers in all waves and applied the rank-4 update with
 // scalar FMAs whose per-column coefficients every wave read as LDS broadcasts: 2 MB of LDS
 // return traffic per block, 1.1 us per 4 pivots of which the pivots themselves were 0.24 us.)
+// The factorisation proper, shared by k_diag64 and k_link: on entry the tile waves hold the Schur
+// complement S (identity-padded, strict upper part zero) in accumulator layout; `pcol`, `hs`, `cs`,
+// `rall` are LDS areas nobody reads any more (they may overlay operand tiles of the caller once all
+// waves have passed the first barrier below).  Writes L into D (lower) and L^-1 into `inv`.
+template <typename T>
+static __device__ __forceinline__ void diag_tail(typename Mx<T>::acc_t (&acc)[2], T* __restrict__ pcol, T* __restrict__ hs,
+                                                  T* __restrict__ cs, T* __restrict__ rall, T* __restrict__ D, int64_t ld,
+                                                  int w, T* __restrict__ inv, int32_t* info, int col_base)
+{
+    using X = Mx<T>;
+    constexpr int LS = SB + 2;       // even pitch: a row's 4 block columns are one 16-byte-aligned pair of stores
+    constexpr int BC = 4;
+    constexpr int NP = SB / BC;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int i = lane;
+    const int g = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave id: provably uniform
+    const bool tile_wave = g < DG_TW;
+    const int br = (g >> 1) & 3, ch = g & 1;
+    const int fcol = lane & 15, fk = lane >> 4;
+    // pcol[b][row][t] and hs[b][row][t]: b = double buffer, t = column within the block of 4
+    auto PC = [&](int b, int row, int t) -> T& { return pcol[(b * SB + row) * BC + t]; };
+    auto HS = [&](int b, int row, int t) -> T& { return hs[(b * SB + row) * BC + t]; };
+    if (tile_wave) {
+        // blocks 0 and 1 for the pivot wave (both in tile column 0)
+        if (ch == 0 && fcol < 2 * BC) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) PC(fcol / BC, br * 16 + X::crow(lane, r), fcol % BC) = acc[0][r];
+        }
+    }
+    lds_barrier();
+    STAMP(2);
+
+    T cv[BC], rr[BC], hsr[BC];                     // pivot wave: this row's block columns, roots, left operand
+#pragma unroll
+    for (int t = 0; t < BC; ++t) { cv[t] = (T)0; rr[t] = (T)1; hsr[t] = (T)0; }
+
+    for (int p = 0; p < NP; ++p) {
+        const int j0 = BC * p, bc0 = j0 >> 4, jb = j0 & 15;
+        if (!tile_wave) {
+            // ---- pivot wave: dependent FP64 ops and nothing else
+            // this row's share of block p as gathered (two 16-byte reads, in flight during the FMAs below)
+            const T* gp = &PC(p & 1, i, 0);
+            T nx[BC];
+#pragma unroll
+            for (int t = 0; t < BC; ++t) nx[t] = gp[t];
+            if (p > 0) {
+                // block p-1's update of block p's columns (the tile waves have not applied it to
+                // what was gathered); rows of block p-1 restart from 0
+                const bool prev_rows = (i >= j0 - BC) && (i < j0);
+#pragma unroll
+                for (int t2 = 0; t2 < BC; ++t2) {
+                    T u = hsr[0] * bcast_lane(cv[0], j0 + t2);
+#pragma unroll
+                    for (int t = 1; t < BC; ++t) u = fma(hsr[t], bcast_lane(cv[t], j0 + t2), u);
+                    nx[t2] = prev_rows ? u : nx[t2] + u;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < BC; ++t) cv[t] = nx[t];
+            int bad = 0;                                                 // 1 + first non-positive pivot of the block
+            const bool in_block = (i >= j0) && (i < j0 + BC);
+#pragma unroll
+            for (int t = 0; t < BC; ++t) {
+                const int j = j0 + t;
+                const T d = bcast_lane(cv[t], j);
+                const T r = rsqrt_refined<T>(d);
+                rr[t] = r;
+                const T h = (i == j) ? r : cv[t] * r;
+                const T nhr = -h * r;
+#pragma unroll
+                for (int t2 = t + 1; t2 < BC; ++t2) {
+                    const T ak = bcast_lane(cv[t], j0 + t2);                // A[k][j] at pivot time
+                    cv[t2] = fma(nhr, ak, (i == j) ? (T)0 : cv[t2]);
+                }
+                if (!(d > (T)0) && bad == 0 && j < w) bad = j + 1;          // uniform: d is a broadcast value
+                hsr[t] = (in_block && i > j) ? (T)0 : nhr;
+            }
+            T* hp = &HS(p & 1, i, 0);
+            T* cp = &cs[i * LS + j0];
+#pragma unroll
+            for (int t = 0; t < BC; ++t) {
+                hp[t] = hsr[t];
+                cp[t] = cv[t];
+            }
+            if (i < BC) rall[j0 + i] = (i == 0) ? rr[0] : (i == 1) ? rr[1] : (i == 2) ? rr[2] : rr[3];
+            lds_barrier();
+            if (bad != 0 && lane == 0) atomicCAS(info, 0, col_base + bad);
+        } else {
+            lds_barrier();
+            // ---- tile waves: block p's rank-4 update of every tile right of (or containing the
+            // rest of) the block, then the gather of block p+2 (updated through block p)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int bc = 2 * ch + c;
+                if (bc >= bc0) {
+                    const int col = bc * 16 + fcol;
+                    if (br == bc0) {                              // rows of the block: their slots right of it restart from 0
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int rin = X::crow(lane, r);
+                            if (rin >= jb && rin < jb + BC && col >= j0 + BC) acc[c][r] = (T)0;
+                        }
+                    }
+                    const T af = HS(p & 1, br * 16 + fcol, fk);
+                    T bf = cs[(bc * 16 + fcol) * LS + j0 + fk];
+                    if (col < j0 + BC) bf = (T)0;                 // columns of the block and left of it are final
+                    acc[c] = mfma_k4(af, bf, acc[c]);
+                }
+            }
+            if (p + 2 < NP) {
+                const int g0 = j0 + 2 * BC, gbc = g0 >> 4, gjb = g0 & 15;     // block p+2
+                if (ch == (gbc >> 1) && fcol >= gjb && fcol < gjb + BC) {
+                    const int c = gbc & 1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        PC(p & 1, br * 16 + X::crow(lane, r), fcol - gjb) = (c == 0) ? acc[0][r] : acc[1][r];
+                }
+            }
+        }
+    }
+    STAMP(3);
+    __syncthreads();
+    for (int e = tid; e < SB * SB; e += DG_NT) {
+        const int r = e >> 6, c = e & 63;
+        if (r < w && c <= r) D[(int64_t)r * ld + c] = cs[r * LS + c] * rall[c];
+        T v = (T)0;
+        if (r < w && c < r) v = cs[c * LS + r] * rall[r];
+        if (r < w && c == r) v = rall[r];
+        inv[e] = v;
+    }
+    STAMP(4);
+}
+
+// LDS of the factorisation proper, in bytes: pivot columns (cs), gathered columns and left operand
+// (double buffered), reciprocal roots.
+template <typename T> struct DiagLds {
+    static constexpr int CS   = SB * (SB + 2) * (int)sizeof(T);
+    static constexpr int PCOL = 2 * SB * 4 * (int)sizeof(T);
+    static constexpr int RALL = SB * (int)sizeof(T);
+};
+
 template <typename T>
 __global__ __launch_bounds__(DG_NT)
 void k_diag64(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow, int kprev,
@@ -296,22 +450,18 @@ void k_diag64(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow, 
     using X = Mx<T>;
     using TL = Tile64<T>;
     using acc_t = typename X::acc_t;
-    constexpr int LS = SB + 2;       // even pitch: a row's 4 block columns are one 16-byte-aligned pair of stores
-    constexpr int BC = 4;
-    constexpr int NP = SB / BC;
     constexpr int TT = 64 * DG_TW;                                            // threads of the tile waves
     static_assert(DG_TW == 8 && DG_NW == 9, "tile ownership below assumes 8 tile waves + 1 pivot wave");
     __shared__ __attribute__((aligned(16))) unsigned char chunk[TL::BYTES];   // Lrow chunk of the prologue
-    __shared__ __attribute__((aligned(16))) T pcol[2][SB][BC];                // gathered pivot columns, double buffered
-    __shared__ __attribute__((aligned(16))) T hs[2][SB][BC];                  // left operand (per row), double buffered
-    __shared__ __attribute__((aligned(16))) T cs[SB * LS];                    // right operand = pivot-time columns, kept
-    __shared__ T rall[SB];
+    __shared__ __attribute__((aligned(16))) unsigned char pcol_[DiagLds<T>::PCOL];   // gathered pivot columns, double buffered
+    __shared__ __attribute__((aligned(16))) unsigned char hs_[DiagLds<T>::PCOL];     // left operand (per row), double buffered
+    __shared__ __attribute__((aligned(16))) unsigned char cs_[DiagLds<T>::CS];       // right operand = pivot-time columns, kept
+    __shared__ __attribute__((aligned(16))) unsigned char rall_[DiagLds<T>::RALL];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int i = lane;
     const int g = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave id: provably uniform
     const bool tile_wave = g < DG_TW;
     const int br = (g >> 1) & 3, ch = g & 1;
-    const int fcol = lane & 15, fk = lane >> 4;
+    const int fcol = lane & 15;
     // latency-bound chain running next to MFMA-bound update workgroups: win issue arbitration
     __builtin_amdgcn_s_setprio(3);
 
@@ -381,114 +531,9 @@ void k_diag64(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow, 
                 if (row < w && col <= row) v = dval[c][r] - pacc[c][r];
                 acc[c][r] = v;
             }
-        // blocks 0 and 1 for the pivot wave (both in tile column 0)
-        if (ch == 0 && fcol < 2 * BC) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pcol[fcol / BC][br * 16 + X::crow(lane, r)][fcol % BC] = acc[0][r];
-        }
     }
-    lds_barrier();
-    STAMP(2);
-
-    T cv[BC], rr[BC], hsr[BC];                     // pivot wave: this row's block columns, roots, left operand
-#pragma unroll
-    for (int t = 0; t < BC; ++t) { cv[t] = (T)0; rr[t] = (T)1; hsr[t] = (T)0; }
-
-    for (int p = 0; p < NP; ++p) {
-        const int j0 = BC * p, bc0 = j0 >> 4, jb = j0 & 15;
-        if (!tile_wave) {
-            // ---- pivot wave: dependent FP64 ops and nothing else
-            // this row's share of block p as gathered (two 16-byte reads, in flight during the FMAs below)
-            const T* gp = &pcol[p & 1][i][0];
-            T nx[BC];
-#pragma unroll
-            for (int t = 0; t < BC; ++t) nx[t] = gp[t];
-            if (p > 0) {
-                // block p-1's update of block p's columns (the tile waves have not applied it to
-                // what was gathered); rows of block p-1 restart from 0
-                const bool prev_rows = (i >= j0 - BC) && (i < j0);
-#pragma unroll
-                for (int t2 = 0; t2 < BC; ++t2) {
-                    T u = hsr[0] * bcast_lane(cv[0], j0 + t2);
-#pragma unroll
-                    for (int t = 1; t < BC; ++t) u = fma(hsr[t], bcast_lane(cv[t], j0 + t2), u);
-                    nx[t2] = prev_rows ? u : nx[t2] + u;
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < BC; ++t) cv[t] = nx[t];
-            int bad = 0;                                                 // 1 + first non-positive pivot of the block
-            const bool in_block = (i >= j0) && (i < j0 + BC);
-#pragma unroll
-            for (int t = 0; t < BC; ++t) {
-                const int j = j0 + t;
-                const T d = bcast_lane(cv[t], j);
-                const T r = rsqrt_refined<T>(d);
-                rr[t] = r;
-                const T h = (i == j) ? r : cv[t] * r;
-                const T nhr = -h * r;
-#pragma unroll
-                for (int t2 = t + 1; t2 < BC; ++t2) {
-                    const T ak = bcast_lane(cv[t], j0 + t2);                // A[k][j] at pivot time
-                    cv[t2] = fma(nhr, ak, (i == j) ? (T)0 : cv[t2]);
-                }
-                if (!(d > (T)0) && bad == 0 && j < w) bad = j + 1;          // uniform: d is a broadcast value
-                hsr[t] = (in_block && i > j) ? (T)0 : nhr;
-            }
-            T* hp = &hs[p & 1][i][0];
-            T* cp = &cs[i * LS + j0];
-#pragma unroll
-            for (int t = 0; t < BC; ++t) {
-                hp[t] = hsr[t];
-                cp[t] = cv[t];
-            }
-            if (i < BC) rall[j0 + i] = (i == 0) ? rr[0] : (i == 1) ? rr[1] : (i == 2) ? rr[2] : rr[3];
-            lds_barrier();
-            if (bad != 0 && lane == 0) atomicCAS(info, 0, col_base + bad);
-        } else {
-            lds_barrier();
-            // ---- tile waves: block p's rank-4 update of every tile right of (or containing the
-            // rest of) the block, then the gather of block p+2 (updated through block p)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int bc = 2 * ch + c;
-                if (bc >= bc0) {
-                    const int col = bc * 16 + fcol;
-                    if (br == bc0) {                              // rows of the block: their slots right of it restart from 0
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int rin = X::crow(lane, r);
-                            if (rin >= jb && rin < jb + BC && col >= j0 + BC) acc[c][r] = (T)0;
-                        }
-                    }
-                    const T af = hs[p & 1][br * 16 + fcol][fk];
-                    T bf = cs[(bc * 16 + fcol) * LS + j0 + fk];
-                    if (col < j0 + BC) bf = (T)0;                 // columns of the block and left of it are final
-                    acc[c] = mfma_k4(af, bf, acc[c]);
-                }
-            }
-            if (p + 2 < NP) {
-                const int g0 = j0 + 2 * BC, gbc = g0 >> 4, gjb = g0 & 15;     // block p+2
-                if (ch == (gbc >> 1) && fcol >= gjb && fcol < gjb + BC) {
-                    const int c = gbc & 1;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        pcol[p & 1][br * 16 + X::crow(lane, r)][fcol - gjb] = (c == 0) ? acc[0][r] : acc[1][r];
-                }
-            }
-        }
-    }
-    STAMP(3);
-    __syncthreads();
-    for (int e = tid; e < SB * SB; e += DG_NT) {
-        const int r = e >> 6, c = e & 63;
-        if (r < w && c <= r) D[(int64_t)r * ld + c] = cs[r * LS + c] * rall[c];
-        T v = (T)0;
-        if (r < w && c < r) v = cs[c * LS + r] * rall[r];
-        if (r < w && c == r) v = rall[r];
-        inv[e] = v;
-    }
-    STAMP(4);
+    diag_tail<T>(acc, reinterpret_cast<T*>(pcol_), reinterpret_cast<T*>(hs_), reinterpret_cast<T*>(cs_),
+                 reinterpret_cast<T*>(rall_), D, ld, w, inv, info, col_base);
 }
 
 // ---------------------------------------------------------------------------
@@ -502,17 +547,17 @@ void k_diag64(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow, 
 // the extra right-hand-side rows of a row-wise solve).
 // ---------------------------------------------------------------------------
 constexpr int TR = 32;   // rows per workgroup of the panel solve
+template <typename T> struct TrsmLds { static constexpr int BYTES = (2 * TR + SB) * Tile64<T>::LROW; };
 
 template <typename T>
-static __device__ __forceinline__ void trsm64_body(T* __restrict__ Prow, int64_t ldp, int mrows, int kw, int kprev,
+static __device__ __forceinline__ void trsm64_body(unsigned char* smem, T* __restrict__ Prow, int64_t ldp, int mrows, int kw, int kprev,
                                                     const T* __restrict__ Lrow, int64_t ldl,
                                                     const T* __restrict__ invL)
 {
     using X = Mx<T>;
     using TL = Tile64<T>;
     using acc_t = typename X::acc_t;
-    // 32 + 32 + 64 rows: 67.6 KB (f64) -- fits next to one resident trailing-update workgroup
-    __shared__ __attribute__((aligned(16))) unsigned char smem[(2 * TR + SB) * TL::LROW];
+    // smem: 32 + 32 + 64 rows = TRSM_LDS bytes: 67.6 KB (f64) -- fits next to one resident trailing-update workgroup
     unsigned char* ps = smem;                          // P_s, then T          (32 rows)
     unsigned char* as = smem + TR * TL::LROW;          // chunk of Pprev       (32 rows)
     unsigned char* bs = smem + 2 * TR * TL::LROW;      // chunk of Lrow, finally invL (64 rows)
@@ -524,14 +569,14 @@ static __device__ __forceinline__ void trsm64_body(T* __restrict__ Prow, int64_t
     const T* Pprev = Prow - kprev;               // the panel's earlier columns of the same rows
 
     STAMP(8);
-    uint4 ra[TR * TL::CPR / 256], rb[SB * TL::CPR / 256];
+    v4u ra[TR * TL::CPR / 256], rb[SB * TL::CPR / 256];
     // the inverted diagonal block is needed last but depends on nothing: requested first, parked in
     // registers, so that its round trip hides behind the whole K loop instead of following it
-    uint4 rinv[SB * TL::CPR / 256];
+    v4u rinv[SB * TL::CPR / 256];
 #pragma unroll
     for (int p = 0; p < SB * TL::CPR / 256; ++p) {
         const int e = tid + 256 * p, r = e / TL::CPR, c = e - r * TL::CPR;
-        rinv[p] = *reinterpret_cast<const uint4*>(invL + r * SB + c * X::EPC);
+        rinv[p] = *reinterpret_cast<const v4u*>(invL + r * SB + c * X::EPC);
     }
     if (kprev > 0) {
         gload_tile64<T, TR>(ra, Pprev, ldp, mrows, SB);
@@ -598,7 +643,183 @@ void k_trsm64(T* __restrict__ P1, int64_t ld1, int M1, int nb1,
     const int64_t ldp = second ? ld2 : ld1;
     const int M = second ? M2 : M1;
     const int row0 = (second ? (int)blockIdx.x - nb1 : (int)blockIdx.x) * TR;
-    trsm64_body<T>(P + (int64_t)row0 * ldp, ldp, min(TR, M - row0), kw, kprev, Lrow, ldl, invL);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TrsmLds<T>::BYTES];
+    trsm64_body<T>(smem, P + (int64_t)row0 * ldp, ldp, min(TR, M - row0), kw, kprev, Lrow, ldl, invL);
+}
+
+// ---------------------------------------------------------------------------
+// One link of the panel chain in ONE launch (round 2).  Sub-block s of the panel has been factored
+// (its inverse is in the workspace); this launch does
+//   workgroups 1..   the panel solve of sub-block s for the rows BELOW the next diagonal block
+//                    (and the carried rows): 32-row workgroups, exactly k_trsm64's body;
+//   workgroup 0      the next diagonal block: its 64 rows' panel solve
+//                    X = (P_s - Pprev Lrow^T) inv(L_ss)^T, the Schur complement
+//                    S = A - [Pprev X][Pprev X]^T of the diagonal block -- every operand chunk serves
+//                    both products from one LDS tile -- and the factorisation of S (diag_tail).
+// The tall solve, which nothing on the chain waits for, runs in the shadow of workgroup 0's pivot
+// loop, and the next diagonal block never waits for a launch of its own: per link
+// max(solve, X + S + pivots) instead of diag + solve.  Operand tiles and the factorisation's LDS
+// areas overlay each other (67.6 KB in all, as the panel solve alone).
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(DG_NT)
+void k_link(T* __restrict__ A, int64_t ld, int n, int c0, int k0, int wn,
+            T* __restrict__ P2, int64_t ld2, int M2, T* __restrict__ ws, int32_t* info,
+            int64_t sk = 0, int64_t sws = 0, int64_t sb = 0)
+{
+    A += (int64_t)blockIdx.y * sk;                   // batch: see k_diag64
+    ws += (int64_t)blockIdx.y * sws;
+    if (P2) P2 += (int64_t)blockIdx.y * sb;
+    info += blockIdx.y;
+    using X = Mx<T>;
+    using TL = Tile64<T>;
+    using acc_t = typename X::acc_t;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TrsmLds<T>::BYTES];
+    const int kprev = c0 - k0;
+    const T* invL = ws + (int64_t)(c0 / SB) * (SB * SB);
+    const T* Lrow = A + (int64_t)c0 * ld + k0;       // rows of the factored diagonal block, earlier panel columns
+    const int r0 = c0 + SB;                          // first row (and column) of the next diagonal block
+    if (blockIdx.x != 0) {
+        if (threadIdx.x >= 256) return;              // the solve uses four waves
+        const int pc = r0 + wn;
+        const int M1 = n - pc, nb1 = (M1 + TR - 1) / TR;
+        const int b = (int)blockIdx.x - 1;
+        const bool second = b >= nb1;
+        T* P = second ? P2 : A + (int64_t)pc * ld + c0;
+        const int64_t ldp = second ? ld2 : ld;
+        const int M = second ? M2 : M1;
+        const int row0 = (second ? b - nb1 : b) * TR;
+        trsm64_body<T>(smem, P + (int64_t)row0 * ldp, ldp, min(TR, M - row0), SB, kprev, Lrow, ld, invL);
+        return;
+    }
+    constexpr int TT = 64 * DG_TW;                   // threads of the tile waves
+    constexpr int NR = SB * TL::CPR / TT;            // 16-byte pieces per thread and 64 x 64 tile
+    static_assert(SB * TL::LROW >= DiagLds<T>::CS, "pivot columns overlay the first operand tile");
+    static_assert(SB * TL::LROW >= 2 * DiagLds<T>::PCOL + DiagLds<T>::RALL, "gather buffers overlay the second operand tile");
+    unsigned char* bufA = smem;                      // own rows' chunk (both operands of S, left operand of T), then T, then X
+    unsigned char* bufB = smem + SB * TL::LROW;      // Lrow chunk, then inv(L_ss)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool tile_wave = g < DG_TW;
+    const int br = (g >> 1) & 3, ch = g & 1;
+    const int fcol = lane & 15;
+    __builtin_amdgcn_s_setprio(3);
+    T* Arow = A + (int64_t)r0 * ld;                  // the next diagonal block's rows
+    T* D = Arow + r0;
+
+    // everything that depends on nothing is requested first: the diagonal block and P_s in
+    // accumulator layout, inv(L_ss) and the first operand chunks in staging registers
+    T dval[2][4], pval[2][4];
+    v4u rI[NR], rA[NR], rB[NR];
+    if (tile_wave) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = br * 16 + X::crow(lane, r), col = (2 * ch + c) * 16 + fcol;
+                dval[c][r] = (row < wn && col <= row) ? D[(int64_t)row * ld + col] : (T)0;
+                pval[c][r] = (row < wn) ? Arow[(int64_t)row * ld + c0 + col] : (T)0;
+            }
+#pragma unroll
+        for (int p = 0; p < NR; ++p) {
+            const int e = tid + TT * p, r = e / TL::CPR, c = e - r * TL::CPR;
+            rI[p] = *reinterpret_cast<const v4u*>(invL + r * SB + c * X::EPC);
+            if (kprev > 0) {
+                rA[p] = (r < wn) ? *reinterpret_cast<const v4u*>(Arow + k0 + (int64_t)r * ld + c * X::EPC) : v4u_zero();
+                rB[p] = *reinterpret_cast<const v4u*>(Lrow + (int64_t)r * ld + c * X::EPC);
+            }
+        }
+    }
+    acc_t accT[2], accS[2];
+    accT[0] = acc_zero<T>(); accT[1] = acc_zero<T>();
+    accS[0] = acc_zero<T>(); accS[1] = acc_zero<T>();
+    for (int kc = 0; kc < kprev; kc += SB) {
+        if (kc) __syncthreads();                     // the previous chunk has been consumed
+        if (tile_wave) {
+#pragma unroll
+            for (int p = 0; p < NR; ++p) {
+                const int e = tid + TT * p, r = e / TL::CPR, c = e - r * TL::CPR;
+                *reinterpret_cast<v4u*>(bufA + r * TL::LROW + c * 16) = rA[p];
+                *reinterpret_cast<v4u*>(bufB + r * TL::LROW + c * 16) = rB[p];
+            }
+        }
+        __syncthreads();
+        if (tile_wave) {
+            if (kc + SB < kprev) {                   // next chunk in flight during the multiplies
+#pragma unroll
+                for (int p = 0; p < NR; ++p) {
+                    const int e = tid + TT * p, r = e / TL::CPR, c = e - r * TL::CPR;
+                    rA[p] = (r < wn) ? *reinterpret_cast<const v4u*>(Arow + k0 + kc + SB + (int64_t)r * ld + c * X::EPC)
+                                     : v4u_zero();
+                    rB[p] = *reinterpret_cast<const v4u*>(Lrow + kc + SB + (int64_t)r * ld + c * X::EPC);
+                }
+            }
+            mma_chunk32<T, false>(accT, bufA, bufB, br, ch, lane);
+            mma_chunk32<T, false>(accS, bufA, bufA, br, ch, lane);
+        }
+    }
+    if (kprev > 0) __syncthreads();
+    // T = P_s - accT (each lane owns its accumulator elements) as the left operand, inv(L_ss) as the right one
+    if (tile_wave) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = br * 16 + X::crow(lane, r), col = (2 * ch + c) * 16 + fcol;
+                *(reinterpret_cast<T*>(bufA + row * TL::LROW) + col) = pval[c][r] - accT[c][r];
+            }
+#pragma unroll
+        for (int p = 0; p < NR; ++p) {
+            const int e = tid + TT * p, r = e / TL::CPR, c = e - r * TL::CPR;
+            *reinterpret_cast<v4u*>(bufB + r * TL::LROW + c * 16) = rI[p];
+        }
+    }
+    __syncthreads();
+    acc_t accX[2];
+    accX[0] = acc_zero<T>(); accX[1] = acc_zero<T>();
+    if (tile_wave) {
+        mma_chunk32<T, true>(accX, bufA, bufB, br, ch, lane);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = br * 16 + X::crow(lane, r), col = (2 * ch + c) * 16 + fcol;
+                if (row < wn) Arow[(int64_t)row * ld + c0 + col] = accX[c][r];
+            }
+    }
+    __syncthreads();                                 // T and inv(L_ss) have been read
+    if (tile_wave) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = br * 16 + X::crow(lane, r), col = (2 * ch + c) * 16 + fcol;
+                *(reinterpret_cast<T*>(bufA + row * TL::LROW) + col) = accX[c][r];     // rows >= wn are zero
+            }
+    }
+    __syncthreads();
+    acc_t acc[2];
+    acc[0] = acc_zero<T>();
+    acc[1] = acc_zero<T>();
+    if (tile_wave) {
+        mma_chunk32<T, false>(accS, bufA, bufA, br, ch, lane);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = br * 16 + X::crow(lane, r), col = (2 * ch + c) * 16 + fcol;
+                T v = (row == col) ? (T)1 : (T)0;                   // identity padding; strict upper part is zero
+                if (row < wn && col <= row) v = dval[c][r] - accS[c][r];
+                acc[c][r] = v;
+            }
+    }
+    // The second tile is dead since the barrier above (gather buffers go there); the first is read
+    // by the last multiply until diag_tail's first barrier, after which the pivot columns overlay it.
+    T* pcol = reinterpret_cast<T*>(bufB);
+    T* hs   = reinterpret_cast<T*>(bufB + DiagLds<T>::PCOL);
+    T* rall = reinterpret_cast<T*>(bufB + 2 * DiagLds<T>::PCOL);
+    diag_tail<T>(acc, pcol, hs, reinterpret_cast<T*>(bufA), rall, D, ld, wn,
+                 ws + (int64_t)(r0 / SB) * (SB * SB), info, r0);
 }
 
 // All four sub-steps of a panel for rows that take no part in the factorisation itself (the
@@ -611,9 +832,10 @@ void k_trsm256(T* __restrict__ P, int64_t ldp, int M, int w, const T* __restrict
 {
     const int row0 = (int)blockIdx.x * TR;
     const int mrows = min(TR, M - row0);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TrsmLds<T>::BYTES];
     for (int c0 = 0; c0 < w; c0 += SB) {
         if (c0) __syncthreads();                 // this workgroup's stores of the previous sub-step are visible
-        trsm64_body<T>(P + (int64_t)row0 * ldp + c0, ldp, mrows, min(SB, w - c0), c0,
+        trsm64_body<T>(smem, P + (int64_t)row0 * ldp + c0, ldp, mrows, min(SB, w - c0), c0,
                        Lpanel + (int64_t)c0 * ldl, ldl, inv64 + (int64_t)(c0 / SB) * (SB * SB));
     }
 }
@@ -648,7 +870,8 @@ void k_invT_step(T* __restrict__ invT, const T* __restrict__ L, int64_t ld, int 
     const int kw = min(SB, n - c0);
     if (kw <= 0) return;
     T* Prow = invT + (int64_t)p * (CIMRGP_NB * CIMRGP_NB) + (int64_t)blockIdx.x * TR * CIMRGP_NB + SB * s;
-    trsm64_body<T>(Prow, CIMRGP_NB, TR, kw, SB * s, L + (int64_t)c0 * ld + k0, ld, inv64 + (int64_t)(c0 / SB) * (SB * SB));
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TrsmLds<T>::BYTES];
+    trsm64_body<T>(smem, Prow, CIMRGP_NB, TR, kw, SB * s, L + (int64_t)c0 * ld + k0, ld, inv64 + (int64_t)(c0 / SB) * (SB * SB));
 }
 
 }  // namespace
@@ -676,6 +899,54 @@ struct PanelGroup {
     int64_t g0 = -1;      // first column of the group's first panel (-1: no group open)
     int left = 0;         // panels of the group still to come, this one included
 };
+
+// The latency-bound chain of one panel [k0, k0 + w) on stream st: the first 64-column diagonal
+// block in a launch of its own, then one k_link per further sub-block (panel solve of sub-block s
+// beside the factorisation of diagonal block s + 1), and the panel solve of the last sub-block.
+// b (m x .., leading dimension ldb): carried rows solved along (second row set), or nullptr.
+// CIMRGP_SPLIT_LINKS=1 (A/B switch) restores round 1's sequence of 4 x (k_diag64, k_trsm64).
+template <typename T>
+static int panel_chain(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, int64_t k0, int64_t w,
+                       T* b, int64_t m, int64_t ldb, PotrfBatch bt, hipStream_t st, const char* fn)
+{
+    static const bool split_links = (getenv("CIMRGP_SPLIT_LINKS") != nullptr);
+    const bool rows = (b != nullptr && m > 0);
+    const unsigned nbatch = (unsigned)bt.count;
+    const int64_t k1 = k0 + w;
+    const int nb2 = rows ? (int)((m + TR - 1) / TR) : 0;
+    for (int64_t c0 = k0; c0 < k1; c0 += SB) {
+        const int sw = (int)((k1 - c0 < SB) ? (k1 - c0) : SB);
+        const int kprev = (int)(c0 - k0);
+        const int64_t pc = c0 + sw;            // first row after this sub-block
+        T* inv = ws + (c0 / SB) * (SB * SB);
+        const T* lrow = kmat + c0 * ld + k0;   // rows of the diagonal block, earlier panel columns
+        if (split_links || c0 == k0) {
+            hipLaunchKernelGGL((k_diag64<T>), dim3(1, nbatch), dim3(DG_NT), 0, st,
+                               kmat + c0 * ld + c0, ld, sw, lrow, kprev, inv, info, (int)c0, bt.sk, bt.sws);
+            CIMRGP_LAUNCH_CHECK(fn);
+        }
+        if (!split_links && pc < k1) {
+            const int wn = (int)((k1 - pc < SB) ? (k1 - pc) : SB);         // next diagonal block of this panel
+            const int64_t m1 = n - (pc + wn);
+            const int nb1 = (int)((m1 + TR - 1) / TR);
+            hipLaunchKernelGGL((k_link<T>), dim3((unsigned)(1 + nb1 + nb2), nbatch), dim3(DG_NT), 0, st,
+                               kmat, ld, (int)n, (int)c0, (int)k0, wn, rows ? b + c0 : (T*)nullptr, ldb, rows ? (int)m : 0,
+                               ws, info, bt.sk, bt.sws, bt.sb);
+            CIMRGP_LAUNCH_CHECK(fn);
+            continue;
+        }
+        const int64_t m1 = n - pc;
+        const int nb1 = (int)((m1 + TR - 1) / TR);
+        if (nb1 + nb2 > 0) {
+            hipLaunchKernelGGL((k_trsm64<T>), dim3((unsigned)(nb1 + nb2), nbatch), dim3(256), 0, st,
+                               kmat + pc * ld + c0, ld, (int)m1, nb1,
+                               rows ? b + c0 : (T*)nullptr, ldb, rows ? (int)m : 0,
+                               sw, kprev, lrow, ld, (const T*)inv, bt.sk, bt.sws, bt.sb);
+            CIMRGP_LAUNCH_CHECK(fn);
+        }
+    }
+    return 0;
+}
 
 // One panel of a row-wise solve  B <- B L^-T : the 256-wide solve of the panel's columns, then
 // the update of the columns right of it.  While more than `pair_above` columns lie beyond the
@@ -714,7 +985,6 @@ static int panel_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info,
 {
     const char* fn = FACTOR ? "cimrgp_potrf" : "cimrgp_trsm_rows";
     const bool rows = (b != nullptr && m > 0);
-    const unsigned nbatch = (unsigned)bt.count;        // equal-sized problems in the same launches (grid.y)
     PanelGroup rows_grp;
     for (int64_t k0 = 0; k0 < n; k0 += CIMRGP_NB) {
         const int64_t w = (n - k0 < CIMRGP_NB) ? (n - k0) : CIMRGP_NB;
@@ -724,27 +994,9 @@ static int panel_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info,
             if (rc) return rc;
             continue;
         }
-        for (int64_t c0 = k0; FACTOR && c0 < k1; c0 += SB) {
-            const int sw = (int)((k1 - c0 < SB) ? (k1 - c0) : SB);
-            const int kprev = (int)(c0 - k0);
-            const int64_t pc = c0 + sw;            // first row after this sub-block
-            T* inv = ws + (c0 / SB) * (SB * SB);
-            const T* lrow = kmat + c0 * ld + k0;   // rows of the diagonal block, earlier panel columns
-            if (FACTOR) {
-                hipLaunchKernelGGL((k_diag64<T>), dim3(1, nbatch), dim3(DG_NT), 0, st,
-                                   kmat + c0 * ld + c0, ld, sw, lrow, kprev, inv, info, (int)c0, bt.sk, bt.sws);
-                CIMRGP_LAUNCH_CHECK(fn);
-            }
-            const int64_t m1 = FACTOR ? (n - pc) : 0;
-            const int nb1 = (int)((m1 + TR - 1) / TR);
-            const int nb2 = rows ? (int)((m + TR - 1) / TR) : 0;
-            if (nb1 + nb2 > 0) {
-                hipLaunchKernelGGL((k_trsm64<T>), dim3((unsigned)(nb1 + nb2), nbatch), dim3(256), 0, st,
-                                   kmat + pc * ld + c0, ld, (int)m1, nb1,
-                                   rows ? b + c0 : nullptr, ldb, rows ? (int)m : 0,
-                                   sw, kprev, lrow, ld, (const T*)inv, bt.sk, bt.sws, bt.sb);
-                CIMRGP_LAUNCH_CHECK(fn);
-            }
+        if (FACTOR) {
+            int rcc = panel_chain<T>(kmat, n, ld, ws, info, k0, w, b, m, ldb, bt, st, fn);
+            if (rcc) return rcc;
         }
         if (n > k1) {
             if (FACTOR) {
@@ -867,27 +1119,7 @@ bool grow_events(LookAhead* la, size_t nevents)
 template <typename T>
 int factor_panel(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, int64_t k0, int64_t w, hipStream_t st)
 {
-    const char* fn = "cimrgp_potrf";
-    const int64_t k1 = k0 + w;
-    for (int64_t c0 = k0; c0 < k1; c0 += SB) {
-        const int sw = (int)((k1 - c0 < SB) ? (k1 - c0) : SB);
-        const int kprev = (int)(c0 - k0);
-        const int64_t pc = c0 + sw;
-        T* inv = ws + (c0 / SB) * (SB * SB);
-        const T* lrow = kmat + c0 * ld + k0;
-        hipLaunchKernelGGL((k_diag64<T>), dim3(1), dim3(DG_NT), 0, st,
-                           kmat + c0 * ld + c0, ld, sw, lrow, kprev, inv, info, (int)c0);
-        CIMRGP_LAUNCH_CHECK(fn);
-        const int64_t m1 = n - pc;
-        const int nb1 = (int)((m1 + TR - 1) / TR);
-        if (nb1 > 0) {
-            hipLaunchKernelGGL((k_trsm64<T>), dim3((unsigned)nb1), dim3(256), 0, st,
-                               kmat + pc * ld + c0, ld, (int)m1, nb1, (T*)nullptr, (int64_t)0, 0,
-                               sw, kprev, lrow, ld, (const T*)inv);
-            CIMRGP_LAUNCH_CHECK(fn);
-        }
-    }
-    return 0;
+    return panel_chain<T>(kmat, n, ld, ws, info, k0, w, (T*)nullptr, 0, 0, PotrfBatch(), st, "cimrgp_potrf");
 }
 }  // namespace
 
