@@ -904,12 +904,18 @@ struct PanelGroup {
 // block in a launch of its own, then one k_link per further sub-block (panel solve of sub-block s
 // beside the factorisation of diagonal block s + 1), and the panel solve of the last sub-block.
 // b (m x .., leading dimension ldb): carried rows solved along (second row set), or nullptr.
-// CIMRGP_SPLIT_LINKS=1 (A/B switch) restores round 1's sequence of 4 x (k_diag64, k_trsm64).
+// `alone`: nothing heavy runs beside the chain (one-queue sweeps, the tail).  A k_link workgroup is
+// dispatched with nine waves, which takes a compute unit BOTH of whose trailing-update workgroups have
+// retired (a four-wave k_trsm64 workgroup fits beside one): next to a running update the links wait
+// for the update's last generation (measured at N = 8192: first link of a panel 230-300 us), so there
+// the chain stays round 1's sequence of 4 x (k_diag64, k_trsm64).
+// CIMRGP_LINKS = 0 / 2 (A/B switch): never / always use the links.
 template <typename T>
 static int panel_chain(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, int64_t k0, int64_t w,
-                       T* b, int64_t m, int64_t ldb, PotrfBatch bt, hipStream_t st, const char* fn)
+                       T* b, int64_t m, int64_t ldb, PotrfBatch bt, hipStream_t st, const char* fn, bool alone)
 {
-    static const bool split_links = (getenv("CIMRGP_SPLIT_LINKS") != nullptr);
+    static const int links_mode = getenv("CIMRGP_LINKS") ? atoi(getenv("CIMRGP_LINKS")) : 1;
+    const bool split_links = (links_mode == 0) || (links_mode == 1 && !alone);
     const bool rows = (b != nullptr && m > 0);
     const unsigned nbatch = (unsigned)bt.count;
     const int64_t k1 = k0 + w;
@@ -995,7 +1001,7 @@ static int panel_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info,
             continue;
         }
         if (FACTOR) {
-            int rcc = panel_chain<T>(kmat, n, ld, ws, info, k0, w, b, m, ldb, bt, st, fn);
+            int rcc = panel_chain<T>(kmat, n, ld, ws, info, k0, w, b, m, ldb, bt, st, fn, true);
             if (rcc) return rcc;
         }
         if (n > k1) {
@@ -1117,9 +1123,9 @@ bool grow_events(LookAhead* la, size_t nevents)
 }
 
 template <typename T>
-int factor_panel(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, int64_t k0, int64_t w, hipStream_t st)
+int factor_panel(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, int64_t k0, int64_t w, hipStream_t st, bool alone)
 {
-    return panel_chain<T>(kmat, n, ld, ws, info, k0, w, (T*)nullptr, 0, 0, PotrfBatch(), st, "cimrgp_potrf");
+    return panel_chain<T>(kmat, n, ld, ws, info, k0, w, (T*)nullptr, 0, 0, PotrfBatch(), st, "cimrgp_potrf", alone);
 }
 }  // namespace
 
@@ -1177,7 +1183,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     CIMRGP_HIP_TRY(hipEventRecord(ev_start, st), "hipEventRecord");
     CIMRGP_HIP_TRY(hipStreamWaitEvent(sp, ev_start, 0), "hipStreamWaitEvent");
     if (sb != st) CIMRGP_HIP_TRY(hipStreamWaitEvent(sb, ev_start, 0), "hipStreamWaitEvent");
-    int rc = factor_panel<T>(k, n, ld, ws, info, 0, (n < CIMRGP_NB) ? n : CIMRGP_NB, sp);
+    int rc = factor_panel<T>(k, n, ld, ws, info, 0, (n < CIMRGP_NB) ? n : CIMRGP_NB, sp, true);
     if (rc) return rc;
     hipEvent_t ev_panel = la->ev[ne++];
     CIMRGP_HIP_TRY(hipEventRecord(ev_panel, sp), "hipEventRecord");
@@ -1185,7 +1191,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     PanelGroup grp;                                    // open group of panels whose far update is still owed
     auto grp_open = [&]() { return grp.g0 >= 0; };
     bool tail_done = false;
-    const int64_t single_tail_below = SINGLE_TAIL_BELOW;
+    static const int64_t single_tail_below = getenv("CIMRGP_TAIL_BELOW") ? atoll(getenv("CIMRGP_TAIL_BELOW")) : SINGLE_TAIL_BELOW;
     hipEvent_t ev_bulk_last = nullptr;                 // last thing queued on the bulk stream
     int64_t rows_next = 0;                             // first panel the carried rows have not seen yet
     // Panel k0 is final (event ev_final): solve + update the carried rows.  They form their own
@@ -1242,7 +1248,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
                                     n - p1, n - p1, (int)pw, true, st);
                 if (rec) (void)hipEventRecord(rec->stop, st);
                 if (rc) return rc;
-                rc = factor_panel<T>(k, n, ld, ws, info, p1, (n - p1 < CIMRGP_NB) ? (n - p1) : CIMRGP_NB, st);
+                rc = factor_panel<T>(k, n, ld, ws, info, p1, (n - p1 < CIMRGP_NB) ? (n - p1) : CIMRGP_NB, st, true);
                 if (rc) return rc;
                 if (rows && la->rows) {
                     ev_fin = la->ev[ne++];
@@ -1270,7 +1276,9 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
                 ev_go = la->ev[ne++];
                 CIMRGP_HIP_TRY(hipEventRecord(ev_go, sp), "hipEventRecord");
             }
-            rc = factor_panel<T>(k, n, ld, ws, info, k1, wn, sp);
+            // links beside a running update only with carried rows (measured, N = 8192 with 2050 rows: 8.87 ms
+            // against 9.14 without links; without rows 6.99 against 6.98, N = 16384: 31.3 against 30.8)
+            rc = factor_panel<T>(k, n, ld, ws, info, k1, wn, sp, rows);
             if (rc) return rc;
             ev_panel = la->ev[ne++];
             CIMRGP_HIP_TRY(hipEventRecord(ev_panel, sp), "hipEventRecord");
