@@ -1043,6 +1043,7 @@ struct LookAhead {
     hipStream_t side = nullptr;        // panel chain (high priority, all compute units)
     hipStream_t bulk = nullptr;        // trailing updates: every compute unit but the reserved ones
     hipStream_t rows = nullptr;        // carried rows: lags behind the factorisation; same mask as bulk
+    hipStream_t rows_far = nullptr;    // carried rows: far part of each panel's update (beside the rows' own panel chain)
     std::vector<hipEvent_t> ev;
     hipStream_t owner = nullptr;       // the caller stream this context was created for
     std::mutex enqueue;                // one factorisation at a time enqueues on this context's queues
@@ -1079,10 +1080,12 @@ LookAhead* make_ctx(int dev)
         if (hipExtStreamCreateWithCUMask(&la->rows, 8, mask) != hipSuccess) la->rows = nullptr;
     }
     if (ok && la->rows == nullptr) ok = hipStreamCreateWithPriority(&la->rows, hipStreamNonBlocking, lo) == hipSuccess;
+    if (ok) ok = hipStreamCreateWithPriority(&la->rows_far, hipStreamNonBlocking, lo) == hipSuccess;
     if (!ok) {
         if (la->side) (void)hipStreamDestroy(la->side);
         if (la->bulk) (void)hipStreamDestroy(la->bulk);
         if (la->rows) (void)hipStreamDestroy(la->rows);
+        if (la->rows_far) (void)hipStreamDestroy(la->rows_far);
         delete la;
         return nullptr;
     }
@@ -1169,7 +1172,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     // Host threads whose streams share a context serialise their ENQUEUE (microseconds); distinct
     // caller streams have distinct contexts and enqueue concurrently.
     std::lock_guard<std::mutex> guard(la->enqueue);
-    if (!grow_events(la, (size_t)(7 * npanels + 12))) return fail("cimrgp_potrf", "hipEventCreate failed");
+    if (!grow_events(la, (size_t)(9 * npanels + 16))) return fail("cimrgp_potrf", "hipEventCreate failed");
     hipStream_t sp = la->side;
     hipStream_t sb = la->bulk ? la->bulk : st;         // bulk trailing updates
     size_t ne = 0;
@@ -1206,6 +1209,8 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     // whose workgroups retire four times as often: 94.8 -> 92.6 posteriors/s; an earlier or later
     // start than 4608 trailing rows: 3072 / 5632 / 6656 / 8192 -> 89.2 / 94.3 / 91.6 / 89.5.)
     PanelGroup rows_grp;                               // carried rows: open group of panels whose far update is owed
+    hipEvent_t ev_rows_far = nullptr;                  // carried rows: last far update queued on the second rows queue
+    static const bool rows_pipeline = (getenv("CIMRGP_ROWS_ONE_QUEUE") == nullptr);    // A/B switch
     auto rows_after_panel = [&](int64_t k0, int64_t k1, hipEvent_t ev_final) -> int {
         if (!rows) return 0;
         hipStream_t sq = la->rows;                     // always present (make_ctx: all queues or no context)
@@ -1214,8 +1219,39 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
         CIMRGP_HIP_TRY(hipStreamWaitEvent(sq, ev_final, 0), "hipStreamWaitEvent");
         // (pairing the rows' updates below that size was measured neutral-to-worse at N = 8192)
         for (int64_t r0 = rows_next; r0 <= k0; r0 += CIMRGP_NB) {
-            int rcr = rows_panel_step<T>(b, ldb, m, k, ld, n, ws, r0, rows_grp, FAR_PAIR_ABOVE, sq, "cimrgp_potrf_rows");
+            const int64_t rw = (n - r0 < CIMRGP_NB) ? (n - r0) : CIMRGP_NB;
+            const int64_t r1 = r0 + rw;
+            const int64_t rn = (n - r1 < CIMRGP_NB) ? (n - r1) : CIMRGP_NB;
+            if (!rows_pipeline || rows_grp.g0 >= 0 || (n > r1 + rn && group_size(n - (r1 + rn), FAR_PAIR_ABOVE) > 1)) {
+                // grouped far updates (large matrices): the rows' chain as one queue
+                if (ev_rows_far) { CIMRGP_HIP_TRY(hipStreamWaitEvent(sq, ev_rows_far, 0), "hipStreamWaitEvent"); ev_rows_far = nullptr; }
+                int rcr = rows_panel_step<T>(b, ldb, m, k, ld, n, ws, r0, rows_grp, FAR_PAIR_ABOVE, sq, "cimrgp_potrf_rows");
+                if (rcr) return rcr;
+                continue;
+            }
+            // The rows' own chain -- 256-wide solve of panel r0 (65 workgroups, 31 us of a nearly idle
+            // machine), then the update of the NEXT panel's columns -- on `sq`; the update of everything
+            // beyond (the bulk of the flops) on a second queue, where it runs beside the next panel's
+            // solve instead of after it.  far(p) needs the solved columns of panel p only; near(p) and
+            // far(p - 1) both write the next panel's columns, so near(p) waits for far(p - 1).
+            hipLaunchKernelGGL((k_trsm256<T>), dim3((unsigned)((m + TR - 1) / TR)), dim3(256), 0, sq,
+                               b + r0, ldb, (int)m, (int)rw, (const T*)(k + r0 * ld + r0), ld,
+                               (const T*)(ws + (r0 / SB) * (SB * SB)));
+            CIMRGP_LAUNCH_CHECK("cimrgp_potrf_rows");
+            if (n <= r1) continue;
+            hipEvent_t ev_w = la->ev[ne++];
+            CIMRGP_HIP_TRY(hipEventRecord(ev_w, sq), "hipEventRecord");
+            if (ev_rows_far) CIMRGP_HIP_TRY(hipStreamWaitEvent(sq, ev_rows_far, 0), "hipStreamWaitEvent");
+            int rcr = gemm_nt_sub<T>(b + r1, ldb, b + r0, ldb, k + r1 * ld + r0, ld, m, rn, (int)rw, false, sq);
             if (rcr) return rcr;
+            if (n > r1 + rn) {
+                hipStream_t sf = la->rows_far;
+                CIMRGP_HIP_TRY(hipStreamWaitEvent(sf, ev_w, 0), "hipStreamWaitEvent");
+                rcr = gemm_nt_sub<T>(b + r1 + rn, ldb, b + r0, ldb, k + (r1 + rn) * ld + r0, ld, m, n - (r1 + rn), (int)rw, false, sf);
+                if (rcr) return rcr;
+                ev_rows_far = la->ev[ne++];
+                CIMRGP_HIP_TRY(hipEventRecord(ev_rows_far, sf), "hipEventRecord");
+            }
         }
         rows_next = k1;
         return 0;
@@ -1343,6 +1379,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
         if (rc) return rc;
     }
     if (rows) {
+        if (ev_rows_far) CIMRGP_HIP_TRY(hipStreamWaitEvent(la->rows, ev_rows_far, 0), "hipStreamWaitEvent");
         hipEvent_t ev_rows_done = la->ev[ne++];
         CIMRGP_HIP_TRY(hipEventRecord(ev_rows_done, la->rows), "hipEventRecord");
         CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_rows_done, 0), "hipStreamWaitEvent");
