@@ -79,7 +79,7 @@ constexpr int SB = 64;   // diagonal sub-block
 // starts above that size.
 constexpr int64_t FAR_PAIR_ABOVE = 8192;
 constexpr int64_t SINGLE_TAIL_BELOW = 4864;  // trailing matrix at or below this: finish on one queue (see potrf_run)
-constexpr int64_t HEAD_FIRST_ABOVE = 4608;   // the bulk update waits for the head update while the trailing matrix is larger
+constexpr int64_t HEAD_FIRST_ABOVE = 1 << 30;   // the bulk update would wait for the head update while the trailing matrix is larger: off (see potrf_run)
 constexpr int64_t ROWS_PAIR_ABOVE_SOLVE = 1024;   // stand-alone row-wise solve: pair the updates while more columns remain
 constexpr int64_t ROWS_START_BELOW = 4608;   // carried rows start once the trailing matrix is smaller than this
 
@@ -170,7 +170,9 @@ static __device__ __forceinline__ void mma_chunk64(typename Mx<T>::acc_t (&acc)[
     const int frow = lane & 15, fslot = lane >> 4;
     const unsigned char* pa = as + (wave * 16 + frow) * TL::LROW + fslot * 8;
     const unsigned char* pb = bs + frow * TL::LROW + fslot * 8;
-#pragma unroll
+    // unrolled by 4 only: fully unrolled, the 80 fragment reads of a chunk are all issued up front and
+    // hold 160 registers (the four-wave kernels must stay within 256 to fit beside an update workgroup)
+#pragma unroll 4
     for (int s = 0; s < TL::NSTEP; ++s) {
         const uint2 a = *reinterpret_cast<const uint2*>(pa + s * 32);
 #pragma unroll
@@ -822,6 +824,394 @@ void k_link(T* __restrict__ A, int64_t ld, int n, int c0, int k0, int wn,
                  ws + (int64_t)(r0 / SB) * (SB * SB), info, r0);
 }
 
+// ---------------------------------------------------------------------------
+// Four-wave forms of the diagonal factorisation and of the link (round 2).  A nine-wave workgroup
+// needs a compute unit that BOTH resident trailing-update workgroups have left (three of its waves
+// share one SIMD's registers), so beside a running update it waits for the update's last generation;
+// a four-wave workgroup (one wave per SIMD, <= 256 registers) fits beside ONE update workgroup and
+// is dispatched, by queue priority, as soon as any update workgroup retires.
+//   waves 0..2   tile waves: the sixteen 16x16 tiles of the combined array dealt round-robin
+//                (tile t = 4 row-tile + column-tile belongs to wave t mod 3: 6 / 5 / 5 tiles);
+//   wave 3       the pivot wave, alone on its SIMD.
+// The left-looking products before the factorisation use all four waves in row-tile layout
+// (wave w = rows 16 w ..: mma_chunk64) and hand the Schur complement over through LDS (`cs`, whose
+// first use inside the loop is the pivot wave's write of block 0 after the first barrier).
+// ---------------------------------------------------------------------------
+constexpr int Q_TW = 3;               // tile waves
+constexpr int Q_NT = 256;             // threads
+constexpr int Q_TILES = 6;            // most tiles one wave owns
+
+template <typename T>
+static __device__ __forceinline__ void diag_tail4(T* __restrict__ pcol, T* __restrict__ hs, T* __restrict__ cs,
+                                                   T* __restrict__ rall, T* __restrict__ D, int64_t ld,
+                                                   int w, T* __restrict__ inv, int32_t* info, int col_base)
+{
+    using X = Mx<T>;
+    using acc_t = typename X::acc_t;
+    constexpr int LS = SB + 2;
+    constexpr int BC = 4;
+    constexpr int NP = SB / BC;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int i = lane;
+    const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool tile_wave = g < Q_TW;
+    const int fcol = lane & 15, fk = lane >> 4;
+    auto PC = [&](int b, int row, int t) -> T& { return pcol[(b * SB + row) * BC + t]; };
+    auto HS = [&](int b, int row, int t) -> T& { return hs[(b * SB + row) * BC + t]; };
+    // on entry `cs` holds the Schur complement S (lower), identity padding beyond w, zeros above
+    acc_t acc[Q_TILES];
+#pragma unroll
+    for (int k = 0; k < Q_TILES; ++k) {
+        acc[k] = acc_zero<T>();
+        const int t = g + Q_TW * k;
+        if (tile_wave && t < 16) {
+            const int br = t >> 2, bc = t & 3;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[k][r] = cs[(br * 16 + X::crow(lane, r)) * LS + bc * 16 + fcol];
+        }
+    }
+    T cv[BC], rr[BC], hsr[BC];
+#pragma unroll
+    for (int t = 0; t < BC; ++t) { cv[t] = (T)0; rr[t] = (T)1; hsr[t] = (T)0; }
+    T first[2][BC];                                  // pivot wave: blocks 0 and 1 straight from S
+    if (!tile_wave) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int t = 0; t < BC; ++t) first[b][t] = cs[i * LS + b * BC + t];
+    }
+    lds_barrier();                                   // every wave has taken its share of S: cs may be overwritten
+
+    for (int p = 0; p < NP; ++p) {
+        const int j0 = BC * p, bc0 = j0 >> 4, jb = j0 & 15;
+        if (!tile_wave) {
+            T nx[BC];
+            if (p < 2) {
+#pragma unroll
+                for (int t = 0; t < BC; ++t) nx[t] = (p == 0) ? first[0][t] : first[1][t];
+            } else {
+                const T* gp = &PC(p & 1, i, 0);
+#pragma unroll
+                for (int t = 0; t < BC; ++t) nx[t] = gp[t];
+            }
+            if (p > 0) {
+                const bool prev_rows = (i >= j0 - BC) && (i < j0);
+#pragma unroll
+                for (int t2 = 0; t2 < BC; ++t2) {
+                    T u = hsr[0] * bcast_lane(cv[0], j0 + t2);
+#pragma unroll
+                    for (int t = 1; t < BC; ++t) u = fma(hsr[t], bcast_lane(cv[t], j0 + t2), u);
+                    nx[t2] = prev_rows ? u : nx[t2] + u;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < BC; ++t) cv[t] = nx[t];
+            int bad = 0;
+            const bool in_block = (i >= j0) && (i < j0 + BC);
+#pragma unroll
+            for (int t = 0; t < BC; ++t) {
+                const int j = j0 + t;
+                const T d = bcast_lane(cv[t], j);
+                const T r = rsqrt_refined<T>(d);
+                rr[t] = r;
+                const T h = (i == j) ? r : cv[t] * r;
+                const T nhr = -h * r;
+#pragma unroll
+                for (int t2 = t + 1; t2 < BC; ++t2) {
+                    const T ak = bcast_lane(cv[t], j0 + t2);
+                    cv[t2] = fma(nhr, ak, (i == j) ? (T)0 : cv[t2]);
+                }
+                if (!(d > (T)0) && bad == 0 && j < w) bad = j + 1;
+                hsr[t] = (in_block && i > j) ? (T)0 : nhr;
+            }
+            T* hp = &HS(p & 1, i, 0);
+            T* cp = &cs[i * LS + j0];
+#pragma unroll
+            for (int t = 0; t < BC; ++t) {
+                hp[t] = hsr[t];
+                cp[t] = cv[t];
+            }
+            if (i < BC) rall[j0 + i] = (i == 0) ? rr[0] : (i == 1) ? rr[1] : (i == 2) ? rr[2] : rr[3];
+            lds_barrier();
+            if (bad != 0 && lane == 0) atomicCAS(info, 0, col_base + bad);
+        } else {
+            lds_barrier();
+            const int g0 = j0 + 2 * BC, gbc = g0 >> 4, gjb = g0 & 15;         // block p+2, gathered below
+#pragma unroll
+            for (int k = 0; k < Q_TILES; ++k) {
+                const int t = g + Q_TW * k;
+                if (t < 16) {
+                    const int br = t >> 2, bc = t & 3;
+                    if (bc >= bc0) {
+                        const int col = bc * 16 + fcol;
+                        if (br == bc0) {                          // rows of the block: their slots right of it restart from 0
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int rin = X::crow(lane, r);
+                                if (rin >= jb && rin < jb + BC && col >= j0 + BC) acc[k][r] = (T)0;
+                            }
+                        }
+                        const T af = HS(p & 1, br * 16 + fcol, fk);
+                        T bf = cs[(bc * 16 + fcol) * LS + j0 + fk];
+                        if (col < j0 + BC) bf = (T)0;             // columns of the block and left of it are final
+                        acc[k] = mfma_k4(af, bf, acc[k]);
+                    }
+                    if (p + 2 < NP && bc == gbc && fcol >= gjb && fcol < gjb + BC) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) PC(p & 1, br * 16 + X::crow(lane, r), fcol - gjb) = acc[k][r];
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < SB * SB; e += Q_NT) {
+        const int r = e >> 6, c = e & 63;
+        if (r < w && c <= r) D[(int64_t)r * ld + c] = cs[r * LS + c] * rall[c];
+        T v = (T)0;
+        if (r < w && c < r) v = cs[c * LS + r] * rall[r];
+        if (r < w && c == r) v = rall[r];
+        inv[e] = v;
+    }
+}
+
+// Schur complement from row-tile accumulators to `cs` (identity padding beyond w, zeros above the diagonal)
+template <typename T>
+static __device__ __forceinline__ void schur_to_lds(T* __restrict__ cs, const T (&dval)[4][4],
+                                                     const typename Mx<T>::acc_t (&sub)[4], int wave, int lane, int w)
+{
+    using X = Mx<T>;
+    constexpr int LS = SB + 2;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = wave * 16 + X::crow(lane, r), col = c * 16 + (lane & 15);
+            T v = (row == col) ? (T)1 : (T)0;
+            if (row < w && col <= row) v = dval[c][r] - sub[c][r];
+            cs[row * LS + col] = v;
+        }
+}
+
+template <typename T>
+__global__ __launch_bounds__(Q_NT, 2)
+void k_diag64q(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow, int kprev,
+               T* __restrict__ inv, int32_t* info, int col_base, int64_t sk = 0, int64_t sws = 0)
+{
+    D += (int64_t)blockIdx.y * sk;
+    Lrow += (int64_t)blockIdx.y * sk;
+    inv += (int64_t)blockIdx.y * sws;
+    info += blockIdx.y;
+    using X = Mx<T>;
+    using TL = Tile64<T>;
+    using acc_t = typename X::acc_t;
+    __shared__ __attribute__((aligned(16))) unsigned char chunk[TL::BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char pcol_[DiagLds<T>::PCOL];
+    __shared__ __attribute__((aligned(16))) unsigned char hs_[DiagLds<T>::PCOL];
+    __shared__ __attribute__((aligned(16))) unsigned char cs_[DiagLds<T>::CS];
+    __shared__ __attribute__((aligned(16))) unsigned char rall_[DiagLds<T>::RALL];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __builtin_amdgcn_s_setprio(3);
+    T dval[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = wave * 16 + X::crow(lane, r), col = c * 16 + (lane & 15);
+            dval[c][r] = (row < w && col <= row) ? D[(int64_t)row * ld + col] : (T)0;
+        }
+    acc_t pacc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) pacc[c] = acc_zero<T>();
+    if (kprev > 0) {
+        constexpr int NR = SB * TL::CPR / Q_NT;
+        v4u regs[NR];
+        auto fetch = [&](int kc) {
+#pragma unroll
+            for (int p = 0; p < NR; ++p) {
+                const int e = tid + Q_NT * p, r = e / TL::CPR, c = e - r * TL::CPR;
+                regs[p] = (r < w) ? *reinterpret_cast<const v4u*>(Lrow + kc + (int64_t)r * ld + c * X::EPC) : v4u_zero();
+            }
+        };
+        fetch(0);
+        for (int kc = 0; kc < kprev; kc += SB) {
+            if (kc) __syncthreads();
+#pragma unroll
+            for (int p = 0; p < NR; ++p) {
+                const int e = tid + Q_NT * p, r = e / TL::CPR, c = e - r * TL::CPR;
+                *reinterpret_cast<v4u*>(chunk + r * TL::LROW + c * 16) = regs[p];
+            }
+            __syncthreads();
+            if (kc + SB < kprev) fetch(kc + SB);
+            mma_chunk64<T, false>(pacc, chunk, chunk, wave, lane);
+        }
+    }
+    schur_to_lds<T>(reinterpret_cast<T*>(cs_), dval, pacc, wave, lane, w);
+    __syncthreads();
+    diag_tail4<T>(reinterpret_cast<T*>(pcol_), reinterpret_cast<T*>(hs_), reinterpret_cast<T*>(cs_),
+                  reinterpret_cast<T*>(rall_), D, ld, w, inv, info, col_base);
+}
+
+// k_link with four-wave workgroups throughout (see k_link for what a link does).
+template <typename T>
+__global__ __launch_bounds__(Q_NT, 2)
+void k_linkq(T* __restrict__ A, int64_t ld, int n, int c0, int k0, int wn,
+             T* __restrict__ P2, int64_t ld2, int M2, T* __restrict__ ws, int32_t* info,
+             int64_t sk = 0, int64_t sws = 0, int64_t sb = 0)
+{
+    A += (int64_t)blockIdx.y * sk;
+    ws += (int64_t)blockIdx.y * sws;
+    if (P2) P2 += (int64_t)blockIdx.y * sb;
+    info += blockIdx.y;
+    using X = Mx<T>;
+    using TL = Tile64<T>;
+    using acc_t = typename X::acc_t;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TrsmLds<T>::BYTES];
+    const int kprev = c0 - k0;
+    const T* invL = ws + (int64_t)(c0 / SB) * (SB * SB);
+    const T* Lrow = A + (int64_t)c0 * ld + k0;
+    const int r0 = c0 + SB;
+    if (blockIdx.x != 0) {
+        const int pc = r0 + wn;
+        const int M1 = n - pc, nb1 = (M1 + TR - 1) / TR;
+        const int b = (int)blockIdx.x - 1;
+        const bool second = b >= nb1;
+        T* P = second ? P2 : A + (int64_t)pc * ld + c0;
+        const int64_t ldp = second ? ld2 : ld;
+        const int M = second ? M2 : M1;
+        const int row0 = (second ? b - nb1 : b) * TR;
+        trsm64_body<T>(smem, P + (int64_t)row0 * ldp, ldp, min(TR, M - row0), SB, kprev, Lrow, ld, invL);
+        return;
+    }
+    constexpr int NR = SB * TL::CPR / Q_NT;
+    static_assert(SB * TL::LROW >= DiagLds<T>::CS, "pivot columns overlay the second operand tile");
+    static_assert(SB * TL::LROW >= 2 * DiagLds<T>::PCOL + DiagLds<T>::RALL, "gather buffers overlay the first operand tile");
+    unsigned char* bufA = smem;
+    unsigned char* bufB = smem + SB * TL::LROW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __builtin_amdgcn_s_setprio(3);
+    T* Arow = A + (int64_t)r0 * ld;
+    T* D = Arow + r0;
+
+    T pval[4][4];
+    v4u rI[NR], rA[NR], rB[NR];
+    // inv(L_ss) is requested when the staging registers of the last operand chunk fall free (the
+    // kernel is held to 256 registers so that a workgroup fits beside a trailing-update workgroup)
+    auto fetch_inv = [&]() {
+#pragma unroll
+        for (int p = 0; p < NR; ++p) {
+            const int e = tid + Q_NT * p, r = e / TL::CPR, c = e - r * TL::CPR;
+            rI[p] = *reinterpret_cast<const v4u*>(invL + r * SB + c * X::EPC);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wave * 16 + X::crow(lane, r), col = c * 16 + (lane & 15);
+                pval[c][r] = (row < wn) ? Arow[(int64_t)row * ld + c0 + col] : (T)0;
+            }
+    };
+    if (kprev > 0) {
+#pragma unroll
+        for (int p = 0; p < NR; ++p) {
+            const int e = tid + Q_NT * p, r = e / TL::CPR, c = e - r * TL::CPR;
+            rA[p] = (r < wn) ? *reinterpret_cast<const v4u*>(Arow + k0 + (int64_t)r * ld + c * X::EPC) : v4u_zero();
+            rB[p] = *reinterpret_cast<const v4u*>(Lrow + (int64_t)r * ld + c * X::EPC);
+        }
+    } else {
+        fetch_inv();
+    }
+    acc_t accT[4], accS[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { accT[c] = acc_zero<T>(); accS[c] = acc_zero<T>(); }
+    auto stage = [&]() {                             // staging registers -> operand tiles
+#pragma unroll
+        for (int p = 0; p < NR; ++p) {
+            const int e = tid + Q_NT * p, r = e / TL::CPR, c = e - r * TL::CPR;
+            *reinterpret_cast<v4u*>(bufA + r * TL::LROW + c * 16) = rA[p];
+            *reinterpret_cast<v4u*>(bufB + r * TL::LROW + c * 16) = rB[p];
+        }
+    };
+    // all chunks but the last: the next chunk in flight during the multiplies
+    for (int kc = 0; kc + SB < kprev; kc += SB) {
+        if (kc) __syncthreads();
+        stage();
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < NR; ++p) {
+            const int e = tid + Q_NT * p, r = e / TL::CPR, c = e - r * TL::CPR;
+            rA[p] = (r < wn) ? *reinterpret_cast<const v4u*>(Arow + k0 + kc + SB + (int64_t)r * ld + c * X::EPC) : v4u_zero();
+            rB[p] = *reinterpret_cast<const v4u*>(Lrow + kc + SB + (int64_t)r * ld + c * X::EPC);
+        }
+        mma_chunk64<T, false>(accT, bufA, bufB, wave, lane);
+        mma_chunk64<T, false>(accS, bufA, bufA, wave, lane);
+    }
+    // the last chunk: inv(L_ss) and P_s in flight instead (the staging registers are free by then)
+    if (kprev > 0) {
+        if (kprev > SB) __syncthreads();
+        stage();
+        __syncthreads();
+        fetch_inv();
+        mma_chunk64<T, false>(accT, bufA, bufB, wave, lane);
+        mma_chunk64<T, false>(accS, bufA, bufA, wave, lane);
+    }
+    if (kprev > 0) __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = wave * 16 + X::crow(lane, r), col = c * 16 + (lane & 15);
+            *(reinterpret_cast<T*>(bufA + row * TL::LROW) + col) = pval[c][r] - accT[c][r];
+        }
+#pragma unroll
+    for (int p = 0; p < NR; ++p) {
+        const int e = tid + Q_NT * p, r = e / TL::CPR, c = e - r * TL::CPR;
+        *reinterpret_cast<v4u*>(bufB + r * TL::LROW + c * 16) = rI[p];
+    }
+    // the diagonal block itself: needed last, requested now that the staging registers are free
+    T dval[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = wave * 16 + X::crow(lane, r), col = c * 16 + (lane & 15);
+            dval[c][r] = (row < wn && col <= row) ? D[(int64_t)row * ld + col] : (T)0;
+        }
+    __syncthreads();
+    acc_t accX[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) accX[c] = acc_zero<T>();
+    mma_chunk64<T, true>(accX, bufA, bufB, wave, lane);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = wave * 16 + X::crow(lane, r), col = c * 16 + (lane & 15);
+            if (row < wn) Arow[(int64_t)row * ld + c0 + col] = accX[c][r];
+        }
+    __syncthreads();                                 // T and inv(L_ss) have been read
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = wave * 16 + X::crow(lane, r), col = c * 16 + (lane & 15);
+            *(reinterpret_cast<T*>(bufA + row * TL::LROW) + col) = accX[c][r];
+        }
+    __syncthreads();
+    mma_chunk64<T, false>(accS, bufA, bufA, wave, lane);
+    // S into the second tile (dead since the barrier above), which becomes `cs`; the first tile is
+    // read by the multiply above until the barrier below and then holds the gather buffers
+    schur_to_lds<T>(reinterpret_cast<T*>(bufB), dval, accS, wave, lane, wn);
+    __syncthreads();
+    T* pcol = reinterpret_cast<T*>(bufA);
+    T* hs   = reinterpret_cast<T*>(bufA + DiagLds<T>::PCOL);
+    T* rall = reinterpret_cast<T*>(bufA + 2 * DiagLds<T>::PCOL);
+    diag_tail4<T>(pcol, hs, reinterpret_cast<T*>(bufB), rall, D, ld, wn,
+                  ws + (int64_t)(r0 / SB) * (SB * SB), info, r0);
+}
+
 // All four sub-steps of a panel for rows that take no part in the factorisation itself (the
 // right-hand-side rows of a row-wise solve): one launch per panel instead of four.  A row
 // block only ever reads its own earlier results, written by this same workgroup.
@@ -904,18 +1294,23 @@ struct PanelGroup {
 // block in a launch of its own, then one k_link per further sub-block (panel solve of sub-block s
 // beside the factorisation of diagonal block s + 1), and the panel solve of the last sub-block.
 // b (m x .., leading dimension ldb): carried rows solved along (second row set), or nullptr.
-// `alone`: nothing heavy runs beside the chain (one-queue sweeps, the tail).  A k_link workgroup is
-// dispatched with nine waves, which takes a compute unit BOTH of whose trailing-update workgroups have
-// retired (a four-wave k_trsm64 workgroup fits beside one): next to a running update the links wait
-// for the update's last generation (measured at N = 8192: first link of a panel 230-300 us), so there
-// the chain stays round 1's sequence of 4 x (k_diag64, k_trsm64).
-// CIMRGP_LINKS = 0 / 2 (A/B switch): never / always use the links.
+// `alone`: nothing heavy runs beside the chain (one-queue sweeps, the tail).  Then the nine-wave
+// kernels are used (a few per cent faster by themselves: N = 2048 1.05 against 1.09 ms).  Beside a
+// running trailing update a nine-wave workgroup is dispatched only to a compute unit BOTH of whose
+// update workgroups have retired -- in effect after the update's last generation (first link of a
+// panel 230-300 us at N = 8192) -- while a four-wave workgroup fits beside one update workgroup and
+// gets, by queue priority, the first slot that falls free: there the four-wave forms run
+// (N = 8192: period of the update-bound panels 437 / 391 / 371 -> 405 / 363 / 355 us).
+// CIMRGP_CHAIN = split | wide | quad (A/B switch): round 1's 4 x (k_diag64, k_trsm64) / nine-wave
+// links everywhere / four-wave links everywhere.
 template <typename T>
 static int panel_chain(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, int64_t k0, int64_t w,
                        T* b, int64_t m, int64_t ldb, PotrfBatch bt, hipStream_t st, const char* fn, bool alone)
 {
-    static const int links_mode = getenv("CIMRGP_LINKS") ? atoi(getenv("CIMRGP_LINKS")) : 1;
-    const bool split_links = (links_mode == 0) || (links_mode == 1 && !alone);
+    static const char* chain_env = getenv("CIMRGP_CHAIN");
+    static const int chain_mode = !chain_env ? 0 : (chain_env[0] == 's' ? 1 : chain_env[0] == 'w' ? 2 : chain_env[0] == 'q' ? 3 : 0);
+    const bool split_links = (chain_mode == 1);
+    const bool waves4 = (chain_mode == 3) || (chain_mode == 0 && !alone);
     const bool rows = (b != nullptr && m > 0);
     const unsigned nbatch = (unsigned)bt.count;
     const int64_t k1 = k0 + w;
@@ -927,17 +1322,26 @@ static int panel_chain(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, int
         T* inv = ws + (c0 / SB) * (SB * SB);
         const T* lrow = kmat + c0 * ld + k0;   // rows of the diagonal block, earlier panel columns
         if (split_links || c0 == k0) {
-            hipLaunchKernelGGL((k_diag64<T>), dim3(1, nbatch), dim3(DG_NT), 0, st,
-                               kmat + c0 * ld + c0, ld, sw, lrow, kprev, inv, info, (int)c0, bt.sk, bt.sws);
+            if (waves4)
+                hipLaunchKernelGGL((k_diag64q<T>), dim3(1, nbatch), dim3(Q_NT), 0, st,
+                                   kmat + c0 * ld + c0, ld, sw, lrow, kprev, inv, info, (int)c0, bt.sk, bt.sws);
+            else
+                hipLaunchKernelGGL((k_diag64<T>), dim3(1, nbatch), dim3(DG_NT), 0, st,
+                                   kmat + c0 * ld + c0, ld, sw, lrow, kprev, inv, info, (int)c0, bt.sk, bt.sws);
             CIMRGP_LAUNCH_CHECK(fn);
         }
         if (!split_links && pc < k1) {
             const int wn = (int)((k1 - pc < SB) ? (k1 - pc) : SB);         // next diagonal block of this panel
             const int64_t m1 = n - (pc + wn);
             const int nb1 = (int)((m1 + TR - 1) / TR);
-            hipLaunchKernelGGL((k_link<T>), dim3((unsigned)(1 + nb1 + nb2), nbatch), dim3(DG_NT), 0, st,
-                               kmat, ld, (int)n, (int)c0, (int)k0, wn, rows ? b + c0 : (T*)nullptr, ldb, rows ? (int)m : 0,
-                               ws, info, bt.sk, bt.sws, bt.sb);
+            if (waves4)
+                hipLaunchKernelGGL((k_linkq<T>), dim3((unsigned)(1 + nb1 + nb2), nbatch), dim3(Q_NT), 0, st,
+                                   kmat, ld, (int)n, (int)c0, (int)k0, wn, rows ? b + c0 : (T*)nullptr, ldb, rows ? (int)m : 0,
+                                   ws, info, bt.sk, bt.sws, bt.sb);
+            else
+                hipLaunchKernelGGL((k_link<T>), dim3((unsigned)(1 + nb1 + nb2), nbatch), dim3(DG_NT), 0, st,
+                                   kmat, ld, (int)n, (int)c0, (int)k0, wn, rows ? b + c0 : (T*)nullptr, ldb, rows ? (int)m : 0,
+                                   ws, info, bt.sk, bt.sws, bt.sb);
             CIMRGP_LAUNCH_CHECK(fn);
             continue;
         }
@@ -1214,7 +1618,8 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     auto rows_after_panel = [&](int64_t k0, int64_t k1, hipEvent_t ev_final) -> int {
         if (!rows) return 0;
         hipStream_t sq = la->rows;                     // always present (make_ctx: all queues or no context)
-        const bool defer = (n - k1 > ROWS_START_BELOW) && (k1 < n);
+        static const int64_t rows_start_below = getenv("CIMRGP_ROWS_START") ? atoll(getenv("CIMRGP_ROWS_START")) : ROWS_START_BELOW;
+        const bool defer = (n - k1 > rows_start_below) && (k1 < n);
         if (defer) return 0;
         CIMRGP_HIP_TRY(hipStreamWaitEvent(sq, ev_final, 0), "hipStreamWaitEvent");
         // (pairing the rows' updates below that size was measured neutral-to-worse at N = 8192)
@@ -1304,17 +1709,18 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
             rc = gemm_nt_sub<T>(k + k1 * ld + k1, ld, k + k1 * ld + k0, ld, k + k1 * ld + k0, ld,
                                 n - k1, wn, (int)w, false, sp);
             if (rc) return rc;
-            // ... and, while the bulk update is big, the head done: started together, the bulk update
-            // takes the compute units from the (small, chain-critical) head and stretches it
-            // five-fold (measured 132 us instead of 27 us at 7680 trailing rows).  With carried rows
-            // the rows' own chain ends last and is served better by an early bulk update.
-            if (!rows && n - k1 > HEAD_FIRST_ABOVE) {
+            // (Round 1 made the bulk update wait for the head while the trailing matrix was large: started
+            // together, the bulk update took the compute units from the head and stretched it five-fold,
+            // and the nine-wave diagonal kernel behind it waited for a whole compute unit.  With the
+            // four-wave chain kernels the order no longer pays -- whole potrf, head first above 4608 rows
+            // against never: N = 8192 6.72 against 6.56 ms, N = 16384 30.39 against 30.08 -- the switch
+            // stays for measurements: CIMRGP_HEAD_FIRST = rows.)
+            static const int64_t head_first_above = getenv("CIMRGP_HEAD_FIRST") ? atoll(getenv("CIMRGP_HEAD_FIRST")) : HEAD_FIRST_ABOVE;
+            if (!rows && n - k1 > head_first_above) {
                 ev_go = la->ev[ne++];
                 CIMRGP_HIP_TRY(hipEventRecord(ev_go, sp), "hipEventRecord");
             }
-            // links beside a running update only with carried rows (measured, N = 8192 with 2050 rows: 8.87 ms
-            // against 9.14 without links; without rows 6.99 against 6.98, N = 16384: 31.3 against 30.8)
-            rc = factor_panel<T>(k, n, ld, ws, info, k1, wn, sp, rows);
+            rc = factor_panel<T>(k, n, ld, ws, info, k1, wn, sp, false);
             if (rc) return rc;
             ev_panel = la->ev[ne++];
             CIMRGP_HIP_TRY(hipEventRecord(ev_panel, sp), "hipEventRecord");
