@@ -102,11 +102,12 @@ def test_potrf_f64_matches_lapack(dev, n):
         assert np.all(np.tril(inv_t[p], -1) == 0)
 
 
-@pytest.mark.parametrize("n,m", [(5184, 0), (5377, 70), (6000, 33), (5632, 0)])
+@pytest.mark.parametrize("n,m", [(5184, 0), (5377, 70), (6000, 33), (5632, 0), (5632, 260), (5500, 385)])
 def test_potrf_lookahead_path_matches_lapack(dev, n, m):
-    """Sizes just above the one-queue limit (5120): the three-queue look-ahead schedule with a
-    ragged last panel (5184 = 20 panels + 64, 5377 = 21 + 1, 6000 = 23 + 112 columns), with and
-    without carried rows, against LAPACK on the whole matrix."""
+    """Sizes just above the one-queue limit (5120): the look-ahead schedule with a ragged last panel
+    (5184 = 20 panels + 64, 5377 = 21 + 1, 6000 = 23 + 112 columns), with and without carried rows,
+    against LAPACK on the whole matrix (m = 260, 385: carried rows a little beyond a multiple of the
+    128-row tile of the far update, which runs on the second rows queue)."""
     rng = np.random.default_rng(n)
     x = np.sort(rng.uniform(-2.0, 2.0, size=(n, 1)), axis=0)
     ell, sf2, noise = 0.05, 1.0, 0.01
