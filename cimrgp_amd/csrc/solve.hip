@@ -238,6 +238,91 @@ void k_bwd_panel(const T* __restrict__ L, int64_t ld, int n, const T* __restrict
 }
 
 // ---------------------------------------------------------------------------
+// Forward panel step in two launches (round 2; see the backward pair below for why):
+//   k_fwd_alpha   z_p = L_pp^-1 w_p = invT_p^T w_p  (column sums over the rows <= column of the upper
+//                 triangular invT_p): 16 workgroups x 16 columns, 64 row parts of 4 rows per column,
+//                 fixed-order reduction in LDS;
+//   k_fwd_update  w[rows below the panel] -= L[rows, panel] z_p : 64 rows per workgroup, 16 lanes per
+//                 row, z_p (w x Q) read once per workgroup.
+// ---------------------------------------------------------------------------
+template <typename T, int Q>
+__global__ __launch_bounds__(ST)
+void k_fwd_alpha(const T* __restrict__ invT, int n, const T* __restrict__ work, T* __restrict__ out, int k0, int w)
+{
+    __shared__ T wsh[Q][PW];
+    __shared__ T red[64][Q][16];
+    const int tid = threadIdx.x;
+    const int c16 = tid & 15, part = tid >> 4;                    // 64 row parts of 4 rows
+    const int col = blockIdx.x * 16 + c16;
+    const T* bp = invT + (int64_t)(k0 / PW) * (PW * PW) + col;
+    T bv[4];
+    const int rbeg = part * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[e] = (rbeg + e <= col) ? bp[(int64_t)(rbeg + e) * PW] : (T)0;
+    for (int e = tid; e < Q * PW; e += ST) {
+        const int c = e / PW, u = e - c * PW;
+        wsh[c][u] = (u < w) ? work[(int64_t)c * n + k0 + u] : (T)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < Q; ++c) {
+        T sv = bv[0] * wsh[c][rbeg];
+#pragma unroll
+        for (int e = 1; e < 4; ++e) sv += bv[e] * wsh[c][rbeg + e];
+        red[part][c][c16] = sv;
+    }
+    __syncthreads();
+    if (tid < Q * 16) {
+        const int c = tid >> 4, u = tid & 15;
+        T sv = (T)0;
+#pragma unroll 8
+        for (int pp = 0; pp < 64; ++pp) sv += red[pp][c][u];
+        const int oc = blockIdx.x * 16 + u;
+        if (oc < w) out[(int64_t)c * n + k0 + oc] = sv;
+    }
+}
+
+template <typename T, int Q>
+__global__ __launch_bounds__(ST)
+void k_fwd_update(const T* __restrict__ L, int64_t ld, int n, T* __restrict__ work, const T* __restrict__ zp, int k0, int w)
+{
+    __shared__ T zs[Q][PW];
+    const int tid = threadIdx.x;
+    const int l16 = tid & 15, slot = tid >> 4;
+    const int r = k0 + w + blockIdx.x * 64 + slot;
+    T lv[16];
+    if (r < n) {
+        const T* lp = L + (int64_t)r * ld + k0 + l16 * 16;
+        if (w == PW) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) lv[e] = lp[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) lv[e] = (l16 * 16 + e < w) ? lp[e] : (T)0;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) lv[e] = (T)0;
+    }
+    for (int e = tid; e < Q * PW; e += ST) {
+        const int c = e / PW, u = e - c * PW;
+        zs[c][u] = (u < w) ? zp[(int64_t)c * n + k0 + u] : (T)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < Q; ++c) {
+        T sv = (T)0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sv += lv[e] * zs[c][l16 * 16 + e];
+        sv += __shfl_xor(sv, 8, 16);
+        sv += __shfl_xor(sv, 4, 16);
+        sv += __shfl_xor(sv, 2, 16);
+        sv += __shfl_xor(sv, 1, 16);
+        if (l16 == 0 && r < n) work[(int64_t)c * n + r] -= sv;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Backward panel step in two narrow-latency launches (round 2): the redundant inverse apply of
 // k_bwd_panel streams 512 KB of invT through EVERY workgroup before its update can start.
 //   k_bwd_alpha   a_p = invT_p w_p : one wave per row of invT_p (upper triangular: columns >= row),
@@ -422,9 +507,21 @@ int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* 
         const int w = (int)((n - k0 < PW) ? (n - k0) : PW);
         const int64_t below = n - (k0 + w);
         const unsigned grid = (unsigned)((below + 63) / 64);
-        CIMRGP_Q_SWITCH(q, hipLaunchKernelGGL((k_fwd_panel<T, QQ>), dim3(grid ? grid : 1), dim3(ST), 0, st, l, ld, (int)n,
-                                              invT, work, res, q, (int)k0, w));
+        static const bool fused_fwd = (getenv("CIMRGP_BWD_FUSED") != nullptr);    // A/B switch: round 1's one-launch panel step
+        if (fused_fwd) {
+            CIMRGP_Q_SWITCH(q, hipLaunchKernelGGL((k_fwd_panel<T, QQ>), dim3(grid ? grid : 1), dim3(ST), 0, st, l, ld, (int)n,
+                                                  invT, work, res, q, (int)k0, w));
+            CIMRGP_LAUNCH_CHECK(fn);
+            continue;
+        }
+        CIMRGP_Q_SWITCH(q, hipLaunchKernelGGL((k_fwd_alpha<T, QQ>), dim3((unsigned)((w + 15) / 16)), dim3(ST), 0, st,
+                                              invT, (int)n, (const T*)work, res, (int)k0, w));
         CIMRGP_LAUNCH_CHECK(fn);
+        if (grid) {
+            CIMRGP_Q_SWITCH(q, hipLaunchKernelGGL((k_fwd_update<T, QQ>), dim3(grid), dim3(ST), 0, st, l, ld, (int)n,
+                                                  work, (const T*)res, (int)k0, w));
+            CIMRGP_LAUNCH_CHECK(fn);
+        }
     }
     if (!backward_only) {
         if (z_out) {
