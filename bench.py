@@ -286,14 +286,14 @@ def main():
         }
         # HBM traffic and matrix-core busy fraction of that kernel, and the Gram builder's written
         # bytes, come from the committed rocprofv3 --pmc passes of this same command (counters cannot
-        # be collected from inside the process being timed): profiles/r02_pmc_bench_n8192.json
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_bench_n8192.json")
+        # be collected from inside the process being timed): profiles/r02b_pmc_bench_n8192.json
+        pmc = os.path.join(ROOT, "profiles", "r02b_pmc_bench_n8192.json")
         if args.dtype == "f64" and n == 8192 and os.path.exists(pmc):
             with open(pmc) as fh:
                 pj = json.load(fh)
             out["roofline"]["traffic"] = pj["trailing_update"]["traffic_bytes_per_launch"]
             out["roofline"]["traffic_unit"] = ("bytes/launch (PMC upper bound: 2*FETCH_SIZE + WRITE_SIZE, separate passes, "
-                                               "profiles/r02_pmc_bench_n8192.json)")
+                                               "profiles/r02b_pmc_bench_n8192.json)")
             mm = [n - 256 * (p + 2) for p in range((n // 256) - 2)]
             out["roofline"]["algorithmic_bytes_per_launch"] = float(np.mean([m * (m + 1) / 2 * 8 * 2 + m * 256 * 8 for m in mm]))
             out["roofline"]["mfma_busy_frac_pmc"] = pj["trailing_update_mfma"]["mfma_busy_frac"]
