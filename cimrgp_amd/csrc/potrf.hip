@@ -1310,7 +1310,9 @@ static int panel_chain(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, int
     static const char* chain_env = getenv("CIMRGP_CHAIN");
     static const int chain_mode = !chain_env ? 0 : (chain_env[0] == 's' ? 1 : chain_env[0] == 'w' ? 2 : chain_env[0] == 'q' ? 3 : 0);
     const bool split_links = (chain_mode == 1);
-    const bool waves4 = (chain_mode == 3) || (chain_mode == 0 && !alone);
+    // (a batch of factorisations in one launch is its own crowd: many link workgroups compete for the
+    // compute units, and the four-wave form packs twice as many of them)
+    const bool waves4 = (chain_mode == 3) || (chain_mode == 0 && (!alone || bt.count > 1));
     const bool rows = (b != nullptr && m > 0);
     const unsigned nbatch = (unsigned)bt.count;
     const int64_t k1 = k0 + w;
