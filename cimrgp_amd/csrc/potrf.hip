@@ -1738,7 +1738,8 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
                 const int64_t wnn = (n - k2 < CIMRGP_NB) ? (n - k2) : CIMRGP_NB;   // panel after next
                 const int64_t k3 = k2 + wnn;
                 if (grp.g0 < 0) {
-                    const int g = group_size(n - k3, FAR_PAIR_ABOVE);
+                    static const int64_t far_pair_above = getenv("CIMRGP_FAR_PAIR") ? atoll(getenv("CIMRGP_FAR_PAIR")) : FAR_PAIR_ABOVE;
+                    const int g = group_size(n - k3, far_pair_above);
                     if (g > 1) { grp.g0 = k0; grp.left = g; }
                 }
                 if (grp.g0 >= 0) {
