@@ -83,6 +83,32 @@ constexpr int64_t HEAD_FIRST_ABOVE = 1 << 30;   // the bulk update would wait fo
 constexpr int64_t ROWS_PAIR_ABOVE_SOLVE = 1024;   // stand-alone row-wise solve: pair the updates while more columns remain
 constexpr int64_t ROWS_START_BELOW = 4608;   // carried rows start once the trailing matrix is smaller than this
 
+// Measurement switches of the schedule, read once from the environment (defaults = the constants
+// above; tools/sweep_links.sh is the sweep they exist for).  Not part of the interface.
+//   CIMRGP_CHAIN = split | wide | quad   round 1's 4 x (k_diag64, k_trsm64) / nine-wave links
+//                                        everywhere / four-wave links everywhere (default: by context)
+//   CIMRGP_TAIL_BELOW, CIMRGP_ROWS_START, CIMRGP_HEAD_FIRST, CIMRGP_FAR_PAIR = rows   the four thresholds
+//   CIMRGP_ROWS_ONE_QUEUE                the carried rows' far updates on the rows' chain queue
+//   CIMRGP_RESERVE_CUS = R               compute units per XCD kept free of the update kernels (make_ctx)
+struct Tuning {
+    int chain_mode = 0;                              // 0 by context, 1 split, 2 nine-wave links, 3 four-wave links
+    int64_t tail_below = SINGLE_TAIL_BELOW, rows_start_below = ROWS_START_BELOW;
+    int64_t head_first_above = HEAD_FIRST_ABOVE, far_pair_above = FAR_PAIR_ABOVE;
+    bool rows_two_queues = true;
+    Tuning()
+    {
+        auto num = [](const char* name, int64_t dflt) { const char* v = getenv(name); return v ? (int64_t)atoll(v) : dflt; };
+        const char* c = getenv("CIMRGP_CHAIN");
+        chain_mode = !c ? 0 : (c[0] == 's' ? 1 : c[0] == 'w' ? 2 : c[0] == 'q' ? 3 : 0);
+        tail_below = num("CIMRGP_TAIL_BELOW", SINGLE_TAIL_BELOW);
+        rows_start_below = num("CIMRGP_ROWS_START", ROWS_START_BELOW);
+        head_first_above = num("CIMRGP_HEAD_FIRST", HEAD_FIRST_ABOVE);
+        far_pair_above = num("CIMRGP_FAR_PAIR", FAR_PAIR_ABOVE);
+        rows_two_queues = (getenv("CIMRGP_ROWS_ONE_QUEUE") == nullptr);
+    }
+};
+static const Tuning& tuning() { static const Tuning t; return t; }
+
 
 // 16 bytes in flight between global memory and LDS.  A first-class vector: arrays of HIP's uint4
 // struct filled from global memory stay in scratch (the optimiser does not split the struct copy).
@@ -1301,14 +1327,12 @@ struct PanelGroup {
 // panel 230-300 us at N = 8192) -- while a four-wave workgroup fits beside one update workgroup and
 // gets, by queue priority, the first slot that falls free: there the four-wave forms run
 // (N = 8192: period of the update-bound panels 437 / 391 / 371 -> 405 / 363 / 355 us).
-// CIMRGP_CHAIN = split | wide | quad (A/B switch): round 1's 4 x (k_diag64, k_trsm64) / nine-wave
-// links everywhere / four-wave links everywhere.
+// (CIMRGP_CHAIN overrides the choice for measurements: see Tuning.)
 template <typename T>
 static int panel_chain(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, int64_t k0, int64_t w,
                        T* b, int64_t m, int64_t ldb, PotrfBatch bt, hipStream_t st, const char* fn, bool alone)
 {
-    static const char* chain_env = getenv("CIMRGP_CHAIN");
-    static const int chain_mode = !chain_env ? 0 : (chain_env[0] == 's' ? 1 : chain_env[0] == 'w' ? 2 : chain_env[0] == 'q' ? 3 : 0);
+    const int chain_mode = tuning().chain_mode;
     const bool split_links = (chain_mode == 1);
     // (a batch of factorisations in one launch is its own crowd: many link workgroups compete for the
     // compute units, and the four-wave form packs twice as many of them)
@@ -1600,7 +1624,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     PanelGroup grp;                                    // open group of panels whose far update is still owed
     auto grp_open = [&]() { return grp.g0 >= 0; };
     bool tail_done = false;
-    static const int64_t single_tail_below = getenv("CIMRGP_TAIL_BELOW") ? atoll(getenv("CIMRGP_TAIL_BELOW")) : SINGLE_TAIL_BELOW;
+    const int64_t single_tail_below = tuning().tail_below;
     hipEvent_t ev_bulk_last = nullptr;                 // last thing queued on the bulk stream
     int64_t rows_next = 0;                             // first panel the carried rows have not seen yet
     // Panel k0 is final (event ev_final): solve + update the carried rows.  They form their own
@@ -1616,11 +1640,11 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     // start than 4608 trailing rows: 3072 / 5632 / 6656 / 8192 -> 89.2 / 94.3 / 91.6 / 89.5.)
     PanelGroup rows_grp;                               // carried rows: open group of panels whose far update is owed
     hipEvent_t ev_rows_far = nullptr;                  // carried rows: last far update queued on the second rows queue
-    static const bool rows_pipeline = (getenv("CIMRGP_ROWS_ONE_QUEUE") == nullptr);    // A/B switch
+    const bool rows_pipeline = tuning().rows_two_queues;
     auto rows_after_panel = [&](int64_t k0, int64_t k1, hipEvent_t ev_final) -> int {
         if (!rows) return 0;
         hipStream_t sq = la->rows;                     // always present (make_ctx: all queues or no context)
-        static const int64_t rows_start_below = getenv("CIMRGP_ROWS_START") ? atoll(getenv("CIMRGP_ROWS_START")) : ROWS_START_BELOW;
+        const int64_t rows_start_below = tuning().rows_start_below;
         const bool defer = (n - k1 > rows_start_below) && (k1 < n);
         if (defer) return 0;
         CIMRGP_HIP_TRY(hipStreamWaitEvent(sq, ev_final, 0), "hipStreamWaitEvent");
@@ -1717,7 +1741,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
             // four-wave chain kernels the order no longer pays -- whole potrf, head first above 4608 rows
             // against never: N = 8192 6.72 against 6.56 ms, N = 16384 30.39 against 30.08 -- the switch
             // stays for measurements: CIMRGP_HEAD_FIRST = rows.)
-            static const int64_t head_first_above = getenv("CIMRGP_HEAD_FIRST") ? atoll(getenv("CIMRGP_HEAD_FIRST")) : HEAD_FIRST_ABOVE;
+            const int64_t head_first_above = tuning().head_first_above;
             if (!rows && n - k1 > head_first_above) {
                 ev_go = la->ev[ne++];
                 CIMRGP_HIP_TRY(hipEventRecord(ev_go, sp), "hipEventRecord");
@@ -1738,7 +1762,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
                 const int64_t wnn = (n - k2 < CIMRGP_NB) ? (n - k2) : CIMRGP_NB;   // panel after next
                 const int64_t k3 = k2 + wnn;
                 if (grp.g0 < 0) {
-                    static const int64_t far_pair_above = getenv("CIMRGP_FAR_PAIR") ? atoll(getenv("CIMRGP_FAR_PAIR")) : FAR_PAIR_ABOVE;
+                    const int64_t far_pair_above = tuning().far_pair_above;
                     const int g = group_size(n - k3, far_pair_above);
                     if (g > 1) { grp.g0 = k0; grp.left = g; }
                 }

@@ -1,15 +1,13 @@
 // D3: alpha = (L L^T)^-1 R for a few right-hand sides (q <= 8), and the D5
 // tail (row reductions over W = K(X*,X) L^-T).
 //
-// The skinny solves walk the 256-column panels: per panel ONE launch in which
-// every workgroup first applies the stored 256x256 inverse of the diagonal block
-// (left in the workspace by potrf, L2-resident) redundantly, one memory round trip,
-// and then subtracts its slice of  L[rows below, panel] z_p  (forward) or
+// The skinny solves walk the 256-column panels: per panel one narrow launch applies
+// the stored 256x256 inverse of the diagonal block (left in the workspace by potrf),
+// a second one subtracts  L[rows below, panel] z_p  (forward) or
 // L[panel, columns left]^T a_p  (backward) from the running right-hand side.
 // Right-hand sides are kept "RHS-major" (q x n) so the updates are coalesced.
 // HBM-read bound: n^2/2 * sizeof(T) bytes per direction.
 #include "common.hpp"
-#include <cstdlib>
 
 namespace cimrgp {
 
@@ -36,208 +34,10 @@ __global__ void k_transpose_nq(const T* __restrict__ src, T* __restrict__ dst, i
 constexpr int PW = CIMRGP_NB;      // panel width of the skinny solves (256)
 constexpr int ST = 1024;           // threads per workgroup of the skinny solves
 
-// Deterministic sum of `parts` partial results held in LDS red[part][c][idx].
-// ---------------------------------------------------------------------------
-// Forward panel step:  z_p = L_pp^-1 w_p ;  w[rows below the panel] -= L[rows, panel] z_p.
-// Every workgroup first forms z_p itself from the stored 256x256 invT_p = (L_pp^-1)^T
-// (column-sum form: thread = column, 4-way split over the rows, all loads independent and
-// coalesced along the row; 512 KB per panel, L2-resident after the first workgroup),
-// workgroup 0 publishes it, then each workgroup updates 64 rows below the panel
-// (16 lanes per row, 16 contiguous elements per lane).
 // ---------------------------------------------------------------------------
 // Q = number of right-hand sides at compile time: a run-time `if (c < q)` inside the load loops
 // is a branch per iteration and serialises the loads (one memory round trip each).
-template <typename T, int Q>
-__global__ __launch_bounds__(ST)
-void k_fwd_panel(const T* __restrict__ L, int64_t ld, int n, const T* __restrict__ invT,
-                 T* __restrict__ work, T* __restrict__ out, int q, int k0, int w)
-{
-    __shared__ T ws_[Q][PW];         // right-hand side of the panel
-    __shared__ T zs[Q][PW];          // solution of the panel
-    __shared__ T red[4][Q][PW];
-    const int tid = threadIdx.x;
-    STAMP(20);
-    for (int e = tid; e < Q * PW; e += ST) {
-        const int c = e / PW, u = e - c * PW;
-        ws_[c][u] = (u < w) ? work[(int64_t)c * n + k0 + u] : (T)0;
-    }
-    __syncthreads();
-    STAMP(21);
-    {
-        const int col = tid & (PW - 1), part = tid >> 8;          // 4 row parts of 64
-        const T* bp = invT + (int64_t)(k0 / PW) * (PW * PW) + col;
-        T acc[Q];
-#pragma unroll
-        for (int c = 0; c < Q; ++c) acc[c] = (T)0;
-        const int rbeg = part * 64;
-        if (rbeg <= col) {                                        // invT is upper triangular: rows <= col
-#pragma unroll 16
-            for (int r = rbeg; r < rbeg + 64; ++r) {
-                const T bv = bp[(int64_t)r * PW];
-#pragma unroll
-                for (int c = 0; c < Q; ++c)
-                    acc[c] += bv * ws_[c][r];
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < Q; ++c)
-            red[part][c][col] = acc[c];
-    }
-    __syncthreads();
-    STAMP(22);
-    for (int e = tid; e < Q * PW; e += ST) {
-        const int c = e / PW, u = e - c * PW;
-        const T v = red[0][c][u] + red[1][c][u] + red[2][c][u] + red[3][c][u];
-        zs[c][u] = v;
-        if (blockIdx.x == 0 && u < w) out[(int64_t)c * n + k0 + u] = v;
-    }
-    __syncthreads();
-    STAMP(23);
-    // 64 rows below the panel per workgroup
-    const int l16 = tid & 15, slot = tid >> 4;
-    const int r = k0 + w + blockIdx.x * 64 + slot;
-    if (r < n) {
-        const T* lp = L + (int64_t)r * ld + k0 + l16 * 16;
-        T sum[Q];
-#pragma unroll
-        for (int c = 0; c < Q; ++c) sum[c] = (T)0;
-        T lv[16];
-        if (w == PW) {                                 // full panel: unconditional, independent loads
-#pragma unroll
-            for (int e = 0; e < 16; ++e) lv[e] = lp[e];
-        } else {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) lv[e] = (l16 * 16 + e < w) ? lp[e] : (T)0;
-        }
-#pragma unroll
-        for (int c = 0; c < Q; ++c)
-            {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) sum[c] += lv[e] * zs[c][l16 * 16 + e];
-            }
-#pragma unroll
-        for (int c = 0; c < Q; ++c) {
-            {
-                T sv = sum[c];
-                sv += __shfl_xor(sv, 8, 16);
-                sv += __shfl_xor(sv, 4, 16);
-                sv += __shfl_xor(sv, 2, 16);
-                sv += __shfl_xor(sv, 1, 16);
-                if (l16 == 0) work[(int64_t)c * n + r] -= sv;
-            }
-        }
-    }
-    STAMP(24);
-}
-
-// ---------------------------------------------------------------------------
-// Backward panel step:  a_p = L_pp^-T w_p = invT_p w_p  (row-dot form) ;
-// w[cols left of the panel] -= L[panel, cols]^T a_p   (thread = column, 16-way split over
-// the panel's rows, 64 columns per workgroup).
-// ---------------------------------------------------------------------------
-template <typename T, int Q>
-__global__ __launch_bounds__(ST)
-void k_bwd_panel(const T* __restrict__ L, int64_t ld, int n, const T* __restrict__ invT,
-                 T* __restrict__ work, T* __restrict__ out, int q, int k0, int w,
-                 int64_t sk = 0, int64_t sws = 0, int64_t sscr = 0)
-{
-    L += (int64_t)blockIdx.y * sk;                   // batch: see k_transpose_nq
-    invT += (int64_t)blockIdx.y * sws;
-    work += (int64_t)blockIdx.y * sscr;
-    out += (int64_t)blockIdx.y * sscr;
-    __shared__ T ws_[Q][PW];
-    __shared__ T zs[Q][PW];
-    __shared__ T red[16][Q][SB];
-    const int tid = threadIdx.x;
-    // this thread's 16 elements of L for the update below: requested first, so that their round
-    // trip overlaps the redundant inverse apply (they do not depend on it)
-    const int t = tid & 63, part = tid >> 6;                      // 16 row parts of 16
-    const int col = blockIdx.x * SB + t;
-    const int ubeg = part * 16;
-    T lv[16];
-    if (col < k0) {
-        const T* lp = L + (int64_t)k0 * ld + col;
-        if (w == PW) {                                 // full panel: unconditional, independent loads
-#pragma unroll
-            for (int e = 0; e < 16; ++e) lv[e] = lp[(int64_t)(ubeg + e) * ld];
-        } else {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) lv[e] = (ubeg + e < w) ? lp[(int64_t)(ubeg + e) * ld] : (T)0;
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) lv[e] = (T)0;
-    }
-    for (int e = tid; e < Q * PW; e += ST) {
-        const int c = e / PW, u = e - c * PW;
-        ws_[c][u] = (u < w) ? work[(int64_t)c * n + k0 + u] : (T)0;
-    }
-    __syncthreads();
-    {
-        const int l16 = tid & 15, slot = tid >> 4;                // 64 rows per pass, 4 passes
-        const T* bp = invT + (int64_t)(k0 / PW) * (PW * PW);
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const int r = slot + 64 * pass;
-            const T* rp = bp + (int64_t)r * PW + l16 * 16;
-            T bv[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) bv[e] = rp[e];
-            T sum[Q];
-#pragma unroll
-            for (int c = 0; c < Q; ++c) sum[c] = (T)0;
-#pragma unroll
-            for (int c = 0; c < Q; ++c)
-                {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) sum[c] += bv[e] * ws_[c][l16 * 16 + e];
-                }
-#pragma unroll
-            for (int c = 0; c < Q; ++c) {
-                {
-                    T sv = sum[c];
-                    sv += __shfl_xor(sv, 8, 16);
-                    sv += __shfl_xor(sv, 4, 16);
-                    sv += __shfl_xor(sv, 2, 16);
-                    sv += __shfl_xor(sv, 1, 16);
-                    if (l16 == 0) {
-                        zs[c][r] = sv;
-                        if (blockIdx.x == 0 && r < w) out[(int64_t)c * n + k0 + r] = sv;
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    T acc[Q];
-#pragma unroll
-    for (int c = 0; c < Q; ++c) acc[c] = (T)0;
-    if (col < k0) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-#pragma unroll
-            for (int c = 0; c < Q; ++c)
-                acc[c] += lv[e] * zs[c][ubeg + e];
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < Q; ++c)
-        red[part][c][t] = acc[c];
-    __syncthreads();
-    if (part == 0 && col < k0) {
-#pragma unroll
-        for (int c = 0; c < Q; ++c) {
-            {
-                T sv = (T)0;
-#pragma unroll
-                for (int pp = 0; pp < 16; ++pp) sv += red[pp][c][t];
-                work[(int64_t)c * n + col] -= sv;
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
+//
 // Forward panel step in two launches (round 2; see the backward pair below for why):
 //   k_fwd_alpha   z_p = L_pp^-1 w_p = invT_p^T w_p  (column sums over the rows <= column of the upper
 //                 triangular invT_p): 16 workgroups x 16 columns, 64 row parts of 4 rows per column,
@@ -323,8 +123,10 @@ void k_fwd_update(const T* __restrict__ L, int64_t ld, int n, T* __restrict__ wo
 }
 
 // ---------------------------------------------------------------------------
-// Backward panel step in two narrow-latency launches (round 2): the redundant inverse apply of
-// k_bwd_panel streams 512 KB of invT through EVERY workgroup before its update can start.
+// Backward panel step in two narrow-latency launches (round 2).  Round 1 used ONE launch per panel
+// in which every workgroup first applied the 256x256 inverse redundantly (512 KB of invT streamed
+// through EVERY workgroup, L2-resident) before its update could start: 23 us per panel against 8.7 us
+// for the pair below (backward solve + prediction tail at N = 8192: 0.82 -> 0.35 ms).
 //   k_bwd_alpha   a_p = invT_p w_p : one wave per row of invT_p (upper triangular: columns >= row),
 //                 2 KB per row, 64 workgroups of 4 rows;
 //   k_bwd_update  w[cols left of the panel] -= L[panel, cols]^T a_p : thread = column, 16-way split
@@ -507,13 +309,6 @@ int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* 
         const int w = (int)((n - k0 < PW) ? (n - k0) : PW);
         const int64_t below = n - (k0 + w);
         const unsigned grid = (unsigned)((below + 63) / 64);
-        static const bool fused_fwd = (getenv("CIMRGP_BWD_FUSED") != nullptr);    // A/B switch: round 1's one-launch panel step
-        if (fused_fwd) {
-            CIMRGP_Q_SWITCH(q, hipLaunchKernelGGL((k_fwd_panel<T, QQ>), dim3(grid ? grid : 1), dim3(ST), 0, st, l, ld, (int)n,
-                                                  invT, work, res, q, (int)k0, w));
-            CIMRGP_LAUNCH_CHECK(fn);
-            continue;
-        }
         CIMRGP_Q_SWITCH(q, hipLaunchKernelGGL((k_fwd_alpha<T, QQ>), dim3((unsigned)((w + 15) / 16)), dim3(ST), 0, st,
                                               invT, (int)n, (const T*)work, res, (int)k0, w));
         CIMRGP_LAUNCH_CHECK(fn);
@@ -532,16 +327,9 @@ int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* 
         if (e != hipSuccess) return check_hip(e, fn, "hipMemcpyAsync");
     }   // backward_only: `work` already holds z (RHS-major), put there by the first transpose
     const int64_t last = ((n - 1) / PW) * PW;
-    static const bool fused_bwd = (getenv("CIMRGP_BWD_FUSED") != nullptr);    // A/B switch: round 1's one-launch panel step
     for (int64_t k0 = last; k0 >= 0; k0 -= PW) {
         const int w = (int)((n - k0 < PW) ? (n - k0) : PW);
         const unsigned grid = (unsigned)((k0 + SB - 1) / SB);
-        if (fused_bwd) {
-            CIMRGP_Q_SWITCH(q, hipLaunchKernelGGL((k_bwd_panel<T, QQ>), dim3(grid ? grid : 1, nbatch), dim3(ST), 0, st, l, ld, (int)n,
-                                                  invT, work, res, q, (int)k0, w, bt.sk, bt.sws, sscr));
-            CIMRGP_LAUNCH_CHECK(fn);
-            continue;
-        }
         CIMRGP_Q_SWITCH(q, hipLaunchKernelGGL((k_bwd_alpha<T, QQ>), dim3((unsigned)((w + 3) / 4), nbatch), dim3(256), 0, st,
                                               invT, (int)n, (const T*)work, res, (int)k0, w, bt.sws, sscr));
         CIMRGP_LAUNCH_CHECK(fn);
