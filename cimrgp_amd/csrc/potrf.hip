@@ -364,6 +364,7 @@ static __device__ __forceinline__ void diag_tail(typename Mx<T>::acc_t (&acc)[2]
         const int j0 = BC * p, bc0 = j0 >> 4, jb = j0 & 15;
         if (!tile_wave) {
             // ---- pivot wave: dependent FP64 ops and nothing else
+            if (p == 8) STAMPW(16, DG_TW);
             // this row's share of block p as gathered (two 16-byte reads, in flight during the FMAs below)
             const T* gp = &PC(p & 1, i, 0);
             T nx[BC];
@@ -383,6 +384,7 @@ static __device__ __forceinline__ void diag_tail(typename Mx<T>::acc_t (&acc)[2]
             }
 #pragma unroll
             for (int t = 0; t < BC; ++t) cv[t] = nx[t];
+            if (p == 8) STAMPW(17, DG_TW);
             int bad = 0;                                                 // 1 + first non-positive pivot of the block
             const bool in_block = (i >= j0) && (i < j0 + BC);
 #pragma unroll
@@ -401,6 +403,7 @@ static __device__ __forceinline__ void diag_tail(typename Mx<T>::acc_t (&acc)[2]
                 if (!(d > (T)0) && bad == 0 && j < w) bad = j + 1;          // uniform: d is a broadcast value
                 hsr[t] = (in_block && i > j) ? (T)0 : nhr;
             }
+            if (p == 8) STAMPW(18, DG_TW);
             T* hp = &HS(p & 1, i, 0);
             T* cp = &cs[i * LS + j0];
 #pragma unroll
@@ -409,10 +412,15 @@ static __device__ __forceinline__ void diag_tail(typename Mx<T>::acc_t (&acc)[2]
                 cp[t] = cv[t];
             }
             if (i < BC) rall[j0 + i] = (i == 0) ? rr[0] : (i == 1) ? rr[1] : (i == 2) ? rr[2] : rr[3];
+            if (p == 8) STAMPW(19, DG_TW);
             lds_barrier();
+            if (p == 8) STAMPW(20, DG_TW);
+            if (p == 9) STAMPW(21, DG_TW);
             if (bad != 0 && lane == 0) atomicCAS(info, 0, col_base + bad);
         } else {
+            if (p == 8) STAMPW(12, 3);
             lds_barrier();
+            if (p == 8) STAMPW(13, 3);
             // ---- tile waves: block p's rank-4 update of every tile right of (or containing the
             // rest of) the block, then the gather of block p+2 (updated through block p)
 #pragma unroll
@@ -442,6 +450,7 @@ static __device__ __forceinline__ void diag_tail(typename Mx<T>::acc_t (&acc)[2]
                         PC(p & 1, br * 16 + X::crow(lane, r), fcol - gjb) = (c == 0) ? acc[0][r] : acc[1][r];
                 }
             }
+            if (p == 8) STAMPW(14, 3);
         }
     }
     STAMP(3);
