@@ -374,11 +374,20 @@ static __device__ __forceinline__ void diag_tail(typename Mx<T>::acc_t (&acc)[2]
                 // block p-1's update of block p's columns (the tile waves have not applied it to
                 // what was gathered); rows of block p-1 restart from 0
                 const bool prev_rows = (i >= j0 - BC) && (i < j0);
+                // the 4 x 4 coefficients = block p-1's pivot-time columns at the rows of block p: this wave
+                // published them in `cs` before the barrier; 8 uniform 16-byte LDS reads, in flight together
+                // with the gathered columns above, instead of 32 v_readlane from its own registers
+                const T* sp = &cs[j0 * LS + j0 - BC];
+                T sm[BC][BC];
+#pragma unroll
+                for (int t2 = 0; t2 < BC; ++t2)
+#pragma unroll
+                    for (int t = 0; t < BC; ++t) sm[t2][t] = sp[t2 * LS + t];
 #pragma unroll
                 for (int t2 = 0; t2 < BC; ++t2) {
-                    T u = hsr[0] * bcast_lane(cv[0], j0 + t2);
+                    T u = hsr[0] * sm[t2][0];
 #pragma unroll
-                    for (int t = 1; t < BC; ++t) u = fma(hsr[t], bcast_lane(cv[t], j0 + t2), u);
+                    for (int t = 1; t < BC; ++t) u = fma(hsr[t], sm[t2][t], u);
                     nx[t2] = prev_rows ? u : nx[t2] + u;
                 }
             }
@@ -931,11 +940,20 @@ static __device__ __forceinline__ void diag_tail4(T* __restrict__ pcol, T* __res
             }
             if (p > 0) {
                 const bool prev_rows = (i >= j0 - BC) && (i < j0);
+                // the 4 x 4 coefficients = block p-1's pivot-time columns at the rows of block p: this wave
+                // published them in `cs` before the barrier; 8 uniform 16-byte LDS reads, in flight together
+                // with the gathered columns above, instead of 32 v_readlane from its own registers
+                const T* sp = &cs[j0 * LS + j0 - BC];
+                T sm[BC][BC];
+#pragma unroll
+                for (int t2 = 0; t2 < BC; ++t2)
+#pragma unroll
+                    for (int t = 0; t < BC; ++t) sm[t2][t] = sp[t2 * LS + t];
 #pragma unroll
                 for (int t2 = 0; t2 < BC; ++t2) {
-                    T u = hsr[0] * bcast_lane(cv[0], j0 + t2);
+                    T u = hsr[0] * sm[t2][0];
 #pragma unroll
-                    for (int t = 1; t < BC; ++t) u = fma(hsr[t], bcast_lane(cv[t], j0 + t2), u);
+                    for (int t = 1; t < BC; ++t) u = fma(hsr[t], sm[t2][t], u);
                     nx[t2] = prev_rows ? u : nx[t2] + u;
                 }
             }
