@@ -726,7 +726,9 @@ void k_link(T* __restrict__ A, int64_t ld, int n, int c0, int k0, int wn,
     const T* Lrow = A + (int64_t)c0 * ld + k0;       // rows of the factored diagonal block, earlier panel columns
     const int r0 = c0 + SB;                          // first row (and column) of the next diagonal block
     if (blockIdx.x != 0) {
-        if (threadIdx.x >= 256) return;              // the solve uses four waves
+        // the solve uses four waves; the other five leave as whole waves (s_barrier counts the waves that
+        // have not terminated, so the body's barriers are among the remaining four)
+        if (threadIdx.x >= 256) return;
         const int pc = r0 + wn;
         const int M1 = n - pc, nb1 = (M1 + TR - 1) / TR;
         const int b = (int)blockIdx.x - 1;
