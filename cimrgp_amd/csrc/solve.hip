@@ -240,13 +240,28 @@ void k_predict_from_w(const T* __restrict__ W, int ns, int n, int64_t ldw, const
 #pragma unroll
     for (int c = 0; c < Q; ++c) sm[c] = (T)0;
     const bool want_mean = (mean != nullptr) && (z != nullptr);
-    for (int j = lane; j < n; j += 64) {
-        const T w = wp[j];
+    // rows start on a 128-byte line (ldw is a multiple of 16 elements): two elements per lane and
+    // load, four independent loads in flight per lane
+    const int n2 = n & ~1;
+#pragma unroll 4
+    for (int j = 2 * lane; j < n2; j += 128) {
+        const T w0 = wp[j], w1 = wp[j + 1];
+        ss += w0 * w0;
+        ss += w1 * w1;
+        if (want_mean) {
+#pragma unroll
+            for (int c = 0; c < Q; ++c) {
+                sm[c] += w0 * z[(int64_t)j * q + c];
+                sm[c] += w1 * z[(int64_t)(j + 1) * q + c];
+            }
+        }
+    }
+    if (n2 < n && lane == 0) {
+        const T w = wp[n2];
         ss += w * w;
         if (want_mean) {
 #pragma unroll
-            for (int c = 0; c < Q; ++c)
-                sm[c] += w * z[(int64_t)j * q + c];
+            for (int c = 0; c < Q; ++c) sm[c] += w * z[(int64_t)n2 * q + c];
         }
     }
 #pragma unroll
