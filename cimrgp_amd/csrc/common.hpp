@@ -114,7 +114,10 @@ int profile_begin();
 int profile_collect(double* total_ms, double* total_flops, int64_t* launches);
 // gemm_nt.hip
 // A batch of independent products in one launch (equal shapes; element strides between problems).
-struct GemmBatch { int count = 1; int64_t sc = 0, sa = 0, sb = 0; };
+// skip_first: the first 64 x 64 tile of a rectangular update is left alone (the chain has already
+// replaced it by its factor; only honoured when the launch uses 64-tiles: gemm_uses_tile64)
+struct GemmBatch { int count = 1; int64_t sc = 0, sa = 0, sb = 0; int skip_first = 0; };
+bool gemm_uses_tile64(int64_t m, int64_t n, bool lower, int count = 1);
 template <typename T> int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t ldb,
                                       int64_t m, int64_t n, int k, bool lower, hipStream_t st, GemmBatch bt = GemmBatch());
 

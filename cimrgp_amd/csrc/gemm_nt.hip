@@ -196,8 +196,9 @@ __global__ __launch_bounds__(256, 2)
 void k_gemm_nt_sub(T* __restrict__ C, int64_t ldc,
                    const T* __restrict__ A, int64_t lda,
                    const T* __restrict__ B, int64_t ldb,
-                   int M, int N, int K, int tiles_n, int64_t sc, int64_t sa, int64_t sb)
+                   int M, int N, int K, int tiles_n, int64_t sc, int64_t sa, int64_t sb, int skip_first)
 {
+    if (skip_first && blockIdx.x == 0) return;        // tile (0, 0) belongs to the chain (see GemmBatch)
     constexpr int GT = 32 * W;
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * GT * LROW];
     // batch of independent products (blocks of one layer): blockIdx.y selects the problem
@@ -234,11 +235,19 @@ static int gemm_launch(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, i
     CIMRGP_REQUIRE(bt.count >= 1 && bt.count < 65536, fn, "batch count out of range");
     const dim3 grid((unsigned)tiles, (unsigned)bt.count);
     if (lower) hipLaunchKernelGGL((k_gemm_nt_sub<T, true, W>), grid, dim3(256), 0, st,
-                                  c, ldc, a, lda, b, ldb, (int)m, (int)n, k, (int)tn, bt.sc, bt.sa, bt.sb);
+                                  c, ldc, a, lda, b, ldb, (int)m, (int)n, k, (int)tn, bt.sc, bt.sa, bt.sb, bt.skip_first);
     else       hipLaunchKernelGGL((k_gemm_nt_sub<T, false, W>), grid, dim3(256), 0, st,
-                                  c, ldc, a, lda, b, ldb, (int)m, (int)n, k, (int)tn, bt.sc, bt.sa, bt.sb);
+                                  c, ldc, a, lda, b, ldb, (int)m, (int)n, k, (int)tn, bt.sc, bt.sa, bt.sb, bt.skip_first);
     CIMRGP_LAUNCH_CHECK(fn);
     return 0;
+}
+
+// The tile-size rule of gemm_nt_sub, for callers that rely on the 64-tile grid (skip_first).
+bool gemm_uses_tile64(int64_t m, int64_t n, bool lower, int count)
+{
+    const int64_t t128 = ((m + 127) / 128) * ((n + 127) / 128) / (lower ? 2 : 1) * count;
+    const int64_t t64 = ((m + 63) / 64) * ((n + 63) / 64) / (lower ? 2 : 1) * count;
+    return !lower && t64 >= 32 && t128 < 768;
 }
 
 template <typename T>
@@ -255,6 +264,7 @@ int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t 
     // each; measured sweep of the switch point inside the factorisation at N = 8192:
     // 256/512/768/1024/1536 tiles -> 91.3/93.5/94.2/91.9/90.6 posteriors/s)
     // (a batch multiplies the number of workgroups: choose the tile for the whole launch)
+    CIMRGP_REQUIRE(!bt.skip_first || gemm_uses_tile64(m, n, lower, bt.count), fn, "skip_first needs a 64-tile launch");
     const int64_t t128 = ((m + 127) / 128) * ((n + 127) / 128) / (lower ? 2 : 1) * bt.count;
     // tiny updates on the factorisation's critical path (the 256 x 256 diagonal block): 32-tiles, so
     // that the K loop of a tile is 1/4 as long and ~36 compute units share it instead of 10

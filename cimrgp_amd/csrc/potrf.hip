@@ -95,6 +95,7 @@ struct Tuning {
     int64_t tail_below = SINGLE_TAIL_BELOW, rows_start_below = ROWS_START_BELOW;
     int64_t head_first_above = HEAD_FIRST_ABOVE, far_pair_above = FAR_PAIR_ABOVE;
     bool rows_two_queues = true;
+    bool fused_head0 = true;                         // CIMRGP_HEAD0=0: the first diagonal block of a panel waits for the head
     Tuning()
     {
         auto num = [](const char* name, int64_t dflt) { const char* v = getenv(name); return v ? (int64_t)atoll(v) : dflt; };
@@ -105,6 +106,7 @@ struct Tuning {
         head_first_above = num("CIMRGP_HEAD_FIRST", HEAD_FIRST_ABOVE);
         far_pair_above = num("CIMRGP_FAR_PAIR", FAR_PAIR_ABOVE);
         rows_two_queues = (getenv("CIMRGP_ROWS_ONE_QUEUE") == nullptr);
+        fused_head0 = num("CIMRGP_HEAD0", 1) != 0;
     }
 };
 static const Tuning& tuning() { static const Tuning t; return t; }
@@ -1359,7 +1361,8 @@ struct PanelGroup {
 // (CIMRGP_CHAIN overrides the choice for measurements: see Tuning.)
 template <typename T>
 static int panel_chain(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, int64_t k0, int64_t w,
-                       T* b, int64_t m, int64_t ldb, PotrfBatch bt, hipStream_t st, const char* fn, bool alone)
+                       T* b, int64_t m, int64_t ldb, PotrfBatch bt, hipStream_t st, const char* fn, bool alone,
+                       bool first_done = false)
 {
     const int chain_mode = tuning().chain_mode;
     const bool split_links = (chain_mode == 1);
@@ -1376,7 +1379,7 @@ static int panel_chain(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, int
         const int64_t pc = c0 + sw;            // first row after this sub-block
         T* inv = ws + (c0 / SB) * (SB * SB);
         const T* lrow = kmat + c0 * ld + k0;   // rows of the diagonal block, earlier panel columns
-        if (split_links || c0 == k0) {
+        if ((split_links || c0 == k0) && !(first_done && c0 == k0)) {
             if (waves4)
                 hipLaunchKernelGGL((k_diag64q<T>), dim3(1, nbatch), dim3(Q_NT), 0, st,
                                    kmat + c0 * ld + c0, ld, sw, lrow, kprev, inv, info, (int)c0, bt.sk, bt.sws);
@@ -1585,9 +1588,10 @@ bool grow_events(LookAhead* la, size_t nevents)
 }
 
 template <typename T>
-int factor_panel(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, int64_t k0, int64_t w, hipStream_t st, bool alone)
+int factor_panel(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, int64_t k0, int64_t w, hipStream_t st, bool alone,
+                 bool first_done = false)
 {
-    return panel_chain<T>(kmat, n, ld, ws, info, k0, w, (T*)nullptr, 0, 0, PotrfBatch(), st, "cimrgp_potrf", alone);
+    return panel_chain<T>(kmat, n, ld, ws, info, k0, w, (T*)nullptr, 0, 0, PotrfBatch(), st, "cimrgp_potrf", alone, first_done);
 }
 }  // namespace
 
@@ -1761,8 +1765,24 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
         if (k1 < n) {
             // chain: head (columns of the next panel, all rows below), then the next panel
             if (ev_rest) CIMRGP_HIP_TRY(hipStreamWaitEvent(sp, ev_rest, 0), "hipStreamWaitEvent");
+            // The next panel's FIRST diagonal block does not wait for the head: one workgroup takes its
+            // update by panel k0 as the left-looking prologue of the diagonal kernel (K = 256) and factors it
+            // -- launched while the machine is still empty (the bulk update of panel k0 starts at the same
+            // moment on the other queue), it does not queue for a slot behind the update's first generation
+            // of workgroups (55 us at N = 8192); the head then leaves that 64 x 64 tile alone.  Whole potrf,
+            // without / with: N = 8192 6.54 / 6.47 ms, N = 16384 30.05 / 29.75; with carried rows it costs
+            // (8.53 -> 8.82 ms with 2050 rows: the rows' queues then see an even busier chain), so not there.
+            const bool head0 = tuning().fused_head0 && !rows && tuning().chain_mode != 1 && w == CIMRGP_NB &&
+                               gemm_uses_tile64(n - k1, wn, false);
+            if (head0) {
+                const int sw0 = (int)((wn < SB) ? wn : SB);
+                hipLaunchKernelGGL((k_diag64q<T>), dim3(1), dim3(Q_NT), 0, sp, k + k1 * ld + k1, ld, sw0,
+                                   (const T*)(k + k1 * ld + k0), (int)w, ws + (k1 / SB) * (SB * SB), info, (int)k1, (int64_t)0, (int64_t)0);
+                CIMRGP_LAUNCH_CHECK("cimrgp_potrf");
+            }
+            GemmBatch ghead; ghead.skip_first = head0 ? 1 : 0;
             rc = gemm_nt_sub<T>(k + k1 * ld + k1, ld, k + k1 * ld + k0, ld, k + k1 * ld + k0, ld,
-                                n - k1, wn, (int)w, false, sp);
+                                n - k1, wn, (int)w, false, sp, ghead);
             if (rc) return rc;
             // (Round 1 made the bulk update wait for the head while the trailing matrix was large: started
             // together, the bulk update took the compute units from the head and stretched it five-fold,
@@ -1775,7 +1795,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
                 ev_go = la->ev[ne++];
                 CIMRGP_HIP_TRY(hipEventRecord(ev_go, sp), "hipEventRecord");
             }
-            rc = factor_panel<T>(k, n, ld, ws, info, k1, wn, sp, false);
+            rc = factor_panel<T>(k, n, ld, ws, info, k1, wn, sp, false, head0);
             if (rc) return rc;
             ev_panel = la->ev[ne++];
             CIMRGP_HIP_TRY(hipEventRecord(ev_panel, sp), "hipEventRecord");
