@@ -824,7 +824,7 @@ void k_link(T* __restrict__ A, int64_t ld, int n, int c0, int k0, int wn,
             *reinterpret_cast<v4u*>(bufB + r * TL::LROW + c * 16) = rI[p];
         }
     }
-    __syncthreads();
+    lds_barrier();
     acc_t accX[2];
     accX[0] = acc_zero<T>(); accX[1] = acc_zero<T>();
     if (tile_wave) {
@@ -837,7 +837,7 @@ void k_link(T* __restrict__ A, int64_t ld, int n, int c0, int k0, int wn,
                 if (row < wn) Arow[(int64_t)row * ld + c0 + col] = accX[c][r];
             }
     }
-    __syncthreads();                                 // T and inv(L_ss) have been read
+    lds_barrier();                                   // T and inv(L_ss) have been read
     if (tile_wave) {
 #pragma unroll
         for (int c = 0; c < 2; ++c)
@@ -847,7 +847,7 @@ void k_link(T* __restrict__ A, int64_t ld, int n, int c0, int k0, int wn,
                 *(reinterpret_cast<T*>(bufA + row * TL::LROW) + col) = accX[c][r];     // rows >= wn are zero
             }
     }
-    __syncthreads();
+    lds_barrier();
     acc_t acc[2];
     acc[0] = acc_zero<T>();
     acc[1] = acc_zero<T>();
@@ -1082,26 +1082,34 @@ void k_diag64q(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow,
 #pragma unroll
     for (int c = 0; c < 4; ++c) pacc[c] = acc_zero<T>();
     if (kprev > 0) {
+        // all (up to four: kprev = 256 when the block takes its head update here) chunks of Lrow are
+        // requested at once: ONE exposed round trip -- beside a running trailing update a dependent global
+        // round trip costs several microseconds, not one
         constexpr int NR = SB * TL::CPR / Q_NT;
-        v4u regs[NR];
-        auto fetch = [&](int kc) {
+        constexpr int MAXC = CIMRGP_NB / SB;
+        v4u regs[MAXC][NR];
 #pragma unroll
-            for (int p = 0; p < NR; ++p) {
-                const int e = tid + Q_NT * p, r = e / TL::CPR, c = e - r * TL::CPR;
-                regs[p] = (r < w) ? *reinterpret_cast<const v4u*>(Lrow + kc + (int64_t)r * ld + c * X::EPC) : v4u_zero();
-            }
-        };
-        fetch(0);
-        for (int kc = 0; kc < kprev; kc += SB) {
-            if (kc) __syncthreads();
+        for (int q = 0; q < MAXC; ++q) {
+            if (q * SB < kprev) {
 #pragma unroll
-            for (int p = 0; p < NR; ++p) {
-                const int e = tid + Q_NT * p, r = e / TL::CPR, c = e - r * TL::CPR;
-                *reinterpret_cast<v4u*>(chunk + r * TL::LROW + c * 16) = regs[p];
+                for (int p = 0; p < NR; ++p) {
+                    const int e = tid + Q_NT * p, r = e / TL::CPR, c = e - r * TL::CPR;
+                    regs[q][p] = (r < w) ? *reinterpret_cast<const v4u*>(Lrow + q * SB + (int64_t)r * ld + c * X::EPC) : v4u_zero();
+                }
             }
-            __syncthreads();
-            if (kc + SB < kprev) fetch(kc + SB);
-            mma_chunk64<T, false>(pacc, chunk, chunk, wave, lane);
+        }
+#pragma unroll
+        for (int q = 0; q < MAXC; ++q) {
+            if (q * SB < kprev) {                      // uniform
+                if (q) __syncthreads();                // the previous chunk has been consumed
+#pragma unroll
+                for (int p = 0; p < NR; ++p) {
+                    const int e = tid + Q_NT * p, r = e / TL::CPR, c = e - r * TL::CPR;
+                    *reinterpret_cast<v4u*>(chunk + r * TL::LROW + c * 16) = regs[q][p];
+                }
+                __syncthreads();
+                mma_chunk64<T, false>(pacc, chunk, chunk, wave, lane);
+            }
         }
     }
     schur_to_lds<T>(reinterpret_cast<T*>(cs_), dval, pacc, wave, lane, w);
@@ -1236,7 +1244,7 @@ void k_linkq(T* __restrict__ A, int64_t ld, int n, int c0, int k0, int wn,
             const int row = wave * 16 + X::crow(lane, r), col = c * 16 + (lane & 15);
             dval[c][r] = (row < wn && col <= row) ? D[(int64_t)row * ld + col] : (T)0;
         }
-    __syncthreads();
+    lds_barrier();
     acc_t accX[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) accX[c] = acc_zero<T>();
@@ -1248,7 +1256,7 @@ void k_linkq(T* __restrict__ A, int64_t ld, int n, int c0, int k0, int wn,
             const int row = wave * 16 + X::crow(lane, r), col = c * 16 + (lane & 15);
             if (row < wn) Arow[(int64_t)row * ld + c0 + col] = accX[c][r];
         }
-    __syncthreads();                                 // T and inv(L_ss) have been read
+    lds_barrier();                                   // T and inv(L_ss) have been read
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -1256,12 +1264,12 @@ void k_linkq(T* __restrict__ A, int64_t ld, int n, int c0, int k0, int wn,
             const int row = wave * 16 + X::crow(lane, r), col = c * 16 + (lane & 15);
             *(reinterpret_cast<T*>(bufA + row * TL::LROW) + col) = accX[c][r];
         }
-    __syncthreads();
+    lds_barrier();
     mma_chunk64<T, false>(accS, bufA, bufA, wave, lane);
     // S into the second tile (dead since the barrier above), which becomes `cs`; the first tile is
     // read by the multiply above until the barrier below and then holds the gather buffers
     schur_to_lds<T>(reinterpret_cast<T*>(bufB), dval, accS, wave, lane, wn);
-    __syncthreads();
+    lds_barrier();
     T* pcol = reinterpret_cast<T*>(bufA);
     T* hs   = reinterpret_cast<T*>(bufA + DiagLds<T>::PCOL);
     T* rall = reinterpret_cast<T*>(bufA + 2 * DiagLds<T>::PCOL);

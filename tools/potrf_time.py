@@ -1,4 +1,4 @@
-"""Time cimrgp_potrf alone at size n (f64): python tools/potrf_time.py n [reps]"""
+"""Time cimrgp_potrf alone at size n (f64): python tools/potrf_time.py n [reps] [stream]"""
 import os
 import sys
 
@@ -10,7 +10,10 @@ import torch
 from cimrgp_amd import device as dev
 
 n = int(sys.argv[1]); reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+own_stream = len(sys.argv) > 3 and sys.argv[3] == "stream"      # run on a non-blocking stream instead of torch's default (null) stream
 dev.require_gpu()
+if own_stream:
+    torch.cuda.set_stream(torch.cuda.Stream())
 rng = np.random.default_rng(0)
 x = torch.as_tensor(np.sort(rng.uniform(-1.7, 1.7, size=(n, 1)), axis=0)).cuda()
 kbuf = dev.alloc_matrix(n, n, torch.float64, "cuda")
