@@ -26,16 +26,19 @@ struct TrailRec { hipEvent_t start, stop; double flops; };
 std::vector<TrailRec> g_recs;
 std::vector<TrailRec> g_free;
 bool g_profile = false;
+std::mutex g_profile_mutex;            // factorisations on different caller streams may be enqueued by different host threads
 }  // namespace
 
 int profile_begin()
 {
+    std::lock_guard<std::mutex> guard(g_profile_mutex);
     g_profile = true;
     return 0;
 }
 
 int profile_collect(double* total_ms, double* total_flops, int64_t* launches)
 {
+    std::lock_guard<std::mutex> guard(g_profile_mutex);
     double ms = 0.0, fl = 0.0;
     int64_t cnt = 0;
     for (auto& r : g_recs) {
@@ -55,8 +58,11 @@ int profile_collect(double* total_ms, double* total_flops, int64_t* launches)
     return 0;
 }
 
-static TrailRec* rec_open(hipStream_t st, double flops)
+// Opens a record (start event on `st`) and returns its stop event, to be recorded behind the launch;
+// nullptr when profiling is off.
+static hipEvent_t rec_open(hipStream_t st, double flops)
 {
+    std::lock_guard<std::mutex> guard(g_profile_mutex);
     if (!g_profile) return nullptr;
     TrailRec r;
     if (!g_free.empty()) { r = g_free.back(); g_free.pop_back(); }
@@ -66,7 +72,7 @@ static TrailRec* rec_open(hipStream_t st, double flops)
     r.flops = flops;
     (void)hipEventRecord(r.start, st);
     g_recs.push_back(r);
-    return &g_recs.back();
+    return r.stop;
 }
 
 namespace {
@@ -1477,11 +1483,11 @@ static int panel_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info,
         if (n > k1) {
             if (FACTOR) {
                 const double mm = (double)(n - k1);
-                TrailRec* rec = rec_open(st, mm * (mm + 1.0) * (double)w * (double)bt.count);   // lower SYRK: M(M+1)K flop
+                hipEvent_t rec = rec_open(st, mm * (mm + 1.0) * (double)w * (double)bt.count);   // lower SYRK: M(M+1)K flop
                 GemmBatch gb; gb.count = bt.count; gb.sc = gb.sa = gb.sb = bt.sk;
                 int rc = gemm_nt_sub<T>(kmat + k1 * ld + k1, ld, kmat + k1 * ld + k0, ld,
                                         kmat + k1 * ld + k0, ld, n - k1, n - k1, (int)w, true, st, gb);
-                if (rec) (void)hipEventRecord(rec->stop, st);
+                if (rec) (void)hipEventRecord(rec, st);
                 if (rc) return rc;
             }
             if (rows) {
@@ -1751,10 +1757,10 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
                 if (rc) return rc;
                 if (p1 >= n) break;
                 const double mm = (double)(n - p1);
-                TrailRec* rec = rec_open(st, mm * (mm + 1.0) * (double)pw);
+                hipEvent_t rec = rec_open(st, mm * (mm + 1.0) * (double)pw);
                 rc = gemm_nt_sub<T>(k + p1 * ld + p1, ld, k + p1 * ld + p0, ld, k + p1 * ld + p0, ld,
                                     n - p1, n - p1, (int)pw, true, st);
-                if (rec) (void)hipEventRecord(rec->stop, st);
+                if (rec) (void)hipEventRecord(rec, st);
                 if (rc) return rc;
                 rc = factor_panel<T>(k, n, ld, ws, info, p1, (n - p1 < CIMRGP_NB) ? (n - p1) : CIMRGP_NB, st, true);
                 if (rc) return rc;
@@ -1840,10 +1846,10 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
                         // which overlaps the chain's next panels
                         if (n > k3) {
                             const double mm = (double)(n - k3);
-                            TrailRec* rec = rec_open(sb, mm * (mm + 1.0) * (double)kk);
+                            hipEvent_t rec = rec_open(sb, mm * (mm + 1.0) * (double)kk);
                             rc = gemm_nt_sub<T>(k + k3 * ld + k3, ld, k + k3 * ld + grp.g0, ld, k + k3 * ld + grp.g0, ld,
                                                 n - k3, n - k3, kk, true, sb);
-                            if (rec) (void)hipEventRecord(rec->stop, sb);
+                            if (rec) (void)hipEventRecord(rec, sb);
                             if (rc) return rc;
                             ev_bulk_last = la->ev[ne++];
                             CIMRGP_HIP_TRY(hipEventRecord(ev_bulk_last, sb), "hipEventRecord");
@@ -1852,10 +1858,10 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
                     }
                 } else {
                     const double mm = (double)(n - k2);
-                    TrailRec* rec = rec_open(sb, mm * (mm + 1.0) * (double)w);
+                    hipEvent_t rec = rec_open(sb, mm * (mm + 1.0) * (double)w);
                     rc = gemm_nt_sub<T>(k + k2 * ld + k2, ld, k + k2 * ld + k0, ld, k + k2 * ld + k0, ld,
                                         n - k2, n - k2, (int)w, true, sb);
-                    if (rec) (void)hipEventRecord(rec->stop, sb);
+                    if (rec) (void)hipEventRecord(rec, sb);
                     if (rc) return rc;
                 }
                 if (!split_far) {
