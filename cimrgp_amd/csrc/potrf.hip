@@ -332,6 +332,72 @@ static __device__ __forceinline__ Mx<float>::acc_t mfma_k4(float a, float b, Mx<
 // (Version 1 kept A in "lane = row" registers in all waves and applied the rank-4 update with
 // scalar FMAs whose per-column coefficients every wave read as LDS broadcasts: 2 MB of LDS
 // return traffic per block, 1.1 us per 4 pivots of which the pivots themselves were 0.24 us.)
+// One block of BC = 4 pivots in the pivot wave (lane = row i), shared by the nine-wave and the four-wave
+// factorisation: takes the block's columns `nx` as gathered (updated through block p-2), applies block
+// p-1's rank-4 update to them itself, eliminates the 4 pivots and publishes the rank-4 update's two
+// operands (hs_row: this row's left operand; cs: the pivot-time columns, kept for all 64 pivots) and the
+// reciprocal roots.  Returns 1 + the first non-positive pivot of the block (0: none).
+template <typename T>
+static __device__ __forceinline__ int pivot_block(int p, T (&nx)[4], T (&cv)[4], T (&rr)[4], T (&hsr)[4],
+                                                   T* __restrict__ hs_row, T* __restrict__ cs, T* __restrict__ rall, int i, int w)
+{
+    constexpr int LS = SB + 2;
+    constexpr int BC = 4;
+    const int j0 = BC * p;
+    if (p > 0) {
+        // block p-1's update of block p's columns (the tile waves have not applied it to what was
+        // gathered); rows of block p-1 restart from 0
+        const bool prev_rows = (i >= j0 - BC) && (i < j0);
+        // the 4 x 4 coefficients = block p-1's pivot-time columns at the rows of block p: this wave
+        // published them in `cs` before the barrier; 8 uniform 16-byte LDS reads, in flight together
+        // with the gathered columns, instead of 32 v_readlane from its own registers
+        const T* sp = &cs[j0 * LS + j0 - BC];
+        T sm[BC][BC];
+#pragma unroll
+        for (int t2 = 0; t2 < BC; ++t2)
+#pragma unroll
+            for (int t = 0; t < BC; ++t) sm[t2][t] = sp[t2 * LS + t];
+#pragma unroll
+        for (int t2 = 0; t2 < BC; ++t2) {
+            T u = hsr[0] * sm[t2][0];
+#pragma unroll
+            for (int t = 1; t < BC; ++t) u = fma(hsr[t], sm[t2][t], u);
+            nx[t2] = prev_rows ? u : nx[t2] + u;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < BC; ++t) cv[t] = nx[t];
+    if (p == 8) STAMPW(17, DG_TW);
+    int bad = 0;
+    const bool in_block = (i >= j0) && (i < j0 + BC);
+#pragma unroll
+    for (int t = 0; t < BC; ++t) {
+        const int j = j0 + t;
+        const T d = bcast_lane(cv[t], j);
+        const T r = rsqrt_refined<T>(d);
+        rr[t] = r;
+        const T h = (i == j) ? r : cv[t] * r;
+        const T nhr = -h * r;
+#pragma unroll
+        for (int t2 = t + 1; t2 < BC; ++t2) {
+            const T ak = bcast_lane(cv[t], j0 + t2);                // A[k][j] at pivot time
+            cv[t2] = fma(nhr, ak, (i == j) ? (T)0 : cv[t2]);
+        }
+        if (!(d > (T)0) && bad == 0 && j < w) bad = j + 1;          // uniform: d is a broadcast value
+        hsr[t] = (in_block && i > j) ? (T)0 : nhr;
+    }
+    if (p == 8) STAMPW(18, DG_TW);
+    T* cp = &cs[i * LS + j0];
+#pragma unroll
+    for (int t = 0; t < BC; ++t) {
+        hs_row[t] = hsr[t];
+        cp[t] = cv[t];
+    }
+    if (i < BC) rall[j0 + i] = (i == 0) ? rr[0] : (i == 1) ? rr[1] : (i == 2) ? rr[2] : rr[3];
+    if (p == 8) STAMPW(19, DG_TW);
+    return bad;
+}
+
 // The factorisation proper, shared by k_diag64 and k_link: on entry the tile waves hold the Schur
 // complement S (identity-padded, strict upper part zero) in accumulator layout; `pcol`, `hs`, `cs`,
 // `rall` are LDS areas nobody reads any more (they may overlay operand tiles of the caller once all
@@ -378,58 +444,7 @@ static __device__ __forceinline__ void diag_tail(typename Mx<T>::acc_t (&acc)[2]
             T nx[BC];
 #pragma unroll
             for (int t = 0; t < BC; ++t) nx[t] = gp[t];
-            if (p > 0) {
-                // block p-1's update of block p's columns (the tile waves have not applied it to
-                // what was gathered); rows of block p-1 restart from 0
-                const bool prev_rows = (i >= j0 - BC) && (i < j0);
-                // the 4 x 4 coefficients = block p-1's pivot-time columns at the rows of block p: this wave
-                // published them in `cs` before the barrier; 8 uniform 16-byte LDS reads, in flight together
-                // with the gathered columns above, instead of 32 v_readlane from its own registers
-                const T* sp = &cs[j0 * LS + j0 - BC];
-                T sm[BC][BC];
-#pragma unroll
-                for (int t2 = 0; t2 < BC; ++t2)
-#pragma unroll
-                    for (int t = 0; t < BC; ++t) sm[t2][t] = sp[t2 * LS + t];
-#pragma unroll
-                for (int t2 = 0; t2 < BC; ++t2) {
-                    T u = hsr[0] * sm[t2][0];
-#pragma unroll
-                    for (int t = 1; t < BC; ++t) u = fma(hsr[t], sm[t2][t], u);
-                    nx[t2] = prev_rows ? u : nx[t2] + u;
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < BC; ++t) cv[t] = nx[t];
-            if (p == 8) STAMPW(17, DG_TW);
-            int bad = 0;                                                 // 1 + first non-positive pivot of the block
-            const bool in_block = (i >= j0) && (i < j0 + BC);
-#pragma unroll
-            for (int t = 0; t < BC; ++t) {
-                const int j = j0 + t;
-                const T d = bcast_lane(cv[t], j);
-                const T r = rsqrt_refined<T>(d);
-                rr[t] = r;
-                const T h = (i == j) ? r : cv[t] * r;
-                const T nhr = -h * r;
-#pragma unroll
-                for (int t2 = t + 1; t2 < BC; ++t2) {
-                    const T ak = bcast_lane(cv[t], j0 + t2);                // A[k][j] at pivot time
-                    cv[t2] = fma(nhr, ak, (i == j) ? (T)0 : cv[t2]);
-                }
-                if (!(d > (T)0) && bad == 0 && j < w) bad = j + 1;          // uniform: d is a broadcast value
-                hsr[t] = (in_block && i > j) ? (T)0 : nhr;
-            }
-            if (p == 8) STAMPW(18, DG_TW);
-            T* hp = &HS(p & 1, i, 0);
-            T* cp = &cs[i * LS + j0];
-#pragma unroll
-            for (int t = 0; t < BC; ++t) {
-                hp[t] = hsr[t];
-                cp[t] = cv[t];
-            }
-            if (i < BC) rall[j0 + i] = (i == 0) ? rr[0] : (i == 1) ? rr[1] : (i == 2) ? rr[2] : rr[3];
-            if (p == 8) STAMPW(19, DG_TW);
+            const int bad = pivot_block<T>(p, nx, cv, rr, hsr, &HS(p & 1, i, 0), cs, rall, i, w);
             lds_barrier();
             if (p == 8) STAMPW(20, DG_TW);
             if (p == 9) STAMPW(21, DG_TW);
@@ -948,53 +963,7 @@ static __device__ __forceinline__ void diag_tail4(T* __restrict__ pcol, T* __res
 #pragma unroll
                 for (int t = 0; t < BC; ++t) nx[t] = gp[t];
             }
-            if (p > 0) {
-                const bool prev_rows = (i >= j0 - BC) && (i < j0);
-                // the 4 x 4 coefficients = block p-1's pivot-time columns at the rows of block p: this wave
-                // published them in `cs` before the barrier; 8 uniform 16-byte LDS reads, in flight together
-                // with the gathered columns above, instead of 32 v_readlane from its own registers
-                const T* sp = &cs[j0 * LS + j0 - BC];
-                T sm[BC][BC];
-#pragma unroll
-                for (int t2 = 0; t2 < BC; ++t2)
-#pragma unroll
-                    for (int t = 0; t < BC; ++t) sm[t2][t] = sp[t2 * LS + t];
-#pragma unroll
-                for (int t2 = 0; t2 < BC; ++t2) {
-                    T u = hsr[0] * sm[t2][0];
-#pragma unroll
-                    for (int t = 1; t < BC; ++t) u = fma(hsr[t], sm[t2][t], u);
-                    nx[t2] = prev_rows ? u : nx[t2] + u;
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < BC; ++t) cv[t] = nx[t];
-            int bad = 0;
-            const bool in_block = (i >= j0) && (i < j0 + BC);
-#pragma unroll
-            for (int t = 0; t < BC; ++t) {
-                const int j = j0 + t;
-                const T d = bcast_lane(cv[t], j);
-                const T r = rsqrt_refined<T>(d);
-                rr[t] = r;
-                const T h = (i == j) ? r : cv[t] * r;
-                const T nhr = -h * r;
-#pragma unroll
-                for (int t2 = t + 1; t2 < BC; ++t2) {
-                    const T ak = bcast_lane(cv[t], j0 + t2);
-                    cv[t2] = fma(nhr, ak, (i == j) ? (T)0 : cv[t2]);
-                }
-                if (!(d > (T)0) && bad == 0 && j < w) bad = j + 1;
-                hsr[t] = (in_block && i > j) ? (T)0 : nhr;
-            }
-            T* hp = &HS(p & 1, i, 0);
-            T* cp = &cs[i * LS + j0];
-#pragma unroll
-            for (int t = 0; t < BC; ++t) {
-                hp[t] = hsr[t];
-                cp[t] = cv[t];
-            }
-            if (i < BC) rall[j0 + i] = (i == 0) ? rr[0] : (i == 1) ? rr[1] : (i == 2) ? rr[2] : rr[3];
+            const int bad = pivot_block<T>(p, nx, cv, rr, hsr, &HS(p & 1, i, 0), cs, rall, i, w);
             lds_barrier();
             if (bad != 0 && lane == 0) atomicCAS(info, 0, col_base + bad);
         } else {
