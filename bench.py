@@ -153,6 +153,12 @@ def main():
         # CIMRGP_BENCH_REHEARSAL=gloo: rehearse the N > 1 path on a box with ONE GPU (all ranks on
         # cuda:0, gloo carrying the device tensors); the driver's multi-GPU runs use nccl = RCCL
         rehearsal = os.environ.get("CIMRGP_BENCH_REHEARSAL", "")
+        # More than one rank: keep every process within the runtime's 4 hardware queues (caller, panel
+        # chain, carried rows + the collective's stream).  With the carried rows' second queue a process
+        # has 5 streams: two such processes SHARING one GPU (the rehearsal) stall for over a second
+        # between steps (measured: 1581 against 22 ms per step), and with one process per GPU the fifth
+        # stream would share a hardware queue -- in order -- with one of the others.  Costs 2 % of a step.
+        os.environ.setdefault("CIMRGP_ROWS_ONE_QUEUE", "1")
         torch.cuda.set_device(0 if rehearsal else local_rank)
         if rehearsal:
             td.init_process_group(rehearsal, rank=rank, world_size=world)

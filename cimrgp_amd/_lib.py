@@ -67,6 +67,12 @@ def load():
             "`python -c 'import __graft_entry__ as g; g.build()'` or "
             "`bash cimrgp_amd/csrc/build.sh` (needs hipcc, --offload-arch=gfx950). "
             "There is no CPU fallback." % LIB_PATH)
+    if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1:
+        # One process of several (torch.distributed launchers export WORLD_SIZE): keep this process within
+        # the runtime's 4 hardware queues -- caller, panel chain, carried rows and the collective's stream.
+        # The factorisation's second carried-rows queue would be a fifth stream; the
+        # library reads the switch at its first factorisation.
+        os.environ.setdefault("CIMRGP_ROWS_ONE_QUEUE", "1")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if a symbol is missing

@@ -94,7 +94,8 @@ constexpr int64_t ROWS_START_BELOW = 4608;   // carried rows start once the trai
 //   CIMRGP_CHAIN = split | wide | quad   round 1's 4 x (k_diag64, k_trsm64) / nine-wave links
 //                                        everywhere / four-wave links everywhere (default: by context)
 //   CIMRGP_TAIL_BELOW, CIMRGP_ROWS_START, CIMRGP_HEAD_FIRST, CIMRGP_FAR_PAIR = rows   the four thresholds
-//   CIMRGP_ROWS_ONE_QUEUE                the carried rows' far updates on the rows' chain queue
+//   CIMRGP_ROWS_ONE_QUEUE                the carried rows' far updates on the rows' chain queue, and no second rows
+//                                        queue is created (for several processes SHARING one GPU: bench.py's rehearsal)
 //   CIMRGP_RESERVE_CUS = R               compute units per XCD kept free of the update kernels (make_ctx)
 struct Tuning {
     int chain_mode = 0;                              // 0 by context, 1 split, 2 nine-wave links, 3 four-wave links
@@ -1525,7 +1526,7 @@ LookAhead* make_ctx(int dev)
         if (hipExtStreamCreateWithCUMask(&la->rows, 8, mask) != hipSuccess) la->rows = nullptr;
     }
     if (ok && la->rows == nullptr) ok = hipStreamCreateWithPriority(&la->rows, hipStreamNonBlocking, lo) == hipSuccess;
-    if (ok) ok = hipStreamCreateWithPriority(&la->rows_far, hipStreamNonBlocking, lo) == hipSuccess;
+    if (ok && tuning().rows_two_queues) ok = hipStreamCreateWithPriority(&la->rows_far, hipStreamNonBlocking, lo) == hipSuccess;
     if (!ok) {
         if (la->side) (void)hipStreamDestroy(la->side);
         if (la->bulk) (void)hipStreamDestroy(la->bulk);
