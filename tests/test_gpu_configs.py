@@ -325,3 +325,23 @@ def test_bench_launches_its_own_ranks(tmp_path):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "weak" and rec["unit"] == "posteriors/s"
     assert rec["value"] > 0 and "roofline" in rec and "cpu_baseline" not in rec
+
+
+def test_rccl_backend_initialises_and_reduces():
+    """Backend "nccl" (= RCCL) with a world of one, bound to the device as bench.py binds it, reducing through
+    cimrgp_amd.dist -- in a process of its own (two ranks cannot share a GPU under RCCL: the 2-rank tests
+    above use gloo)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        env["MASTER_PORT"] = str(sk.getsockname()[1])
+    env["MASTER_ADDR"] = "127.0.0.1"
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "nccl_selftest.py")], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "nccl world 1 ok 66.0 1.5" in out.stdout
