@@ -12,6 +12,9 @@ all-reduce of the fused [mean | var] buffer (RCCL over xGMI).
     python bench.py --gpus N ...          # WORLD_SIZE unset: spawns its own N ranks (see launch_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --config 4 --gpus N [--n 8192]   # BASELINE configs[3]: the sharded 2-D hierarchy (run_config)
+    python bench.py --nccl-world1                    # the N = 1 step with backend nccl (RCCL) initialised and the
+                                                     # fused buffer reduced unconditionally (one-GPU RCCL evidence)
 """
 import argparse
 import ctypes
@@ -124,6 +127,127 @@ def launch_ranks(args):
     return rc
 
 
+def run_config(args, world, rank, rehearsal):
+    """BASELINE configs[2] / configs[3]: the multiresolution hierarchy end to end through the host API, its
+    (resolution, partition) blocks sharded over the ranks (dist.assign_blocks: longest processing time
+    first), one all-reduce per layer of the layer's training-point prediction (Stats.py:126-157) and ONE of
+    the fused [mean | var] buffer at prediction (MRGP.py:802-803).  Total work is fixed as ranks are added
+    (strong scaling).  Rank 0 prints ONE JSON line; at n <= 16384 (or --check) the result is compared with
+    the CPU oracle on the same arrays."""
+    import torch
+    import torch.distributed as td
+    import cimrgp_amd as ca
+    q = 2
+    if args.config == 3:
+        n = args.n or 65536
+        res, d, power = 4, 1, 0
+        x, y, xs = workloads.make_chain_1d(n, q)
+        ells = workloads.chain_length_scales(res + 1, 1)
+        name = "BASELINE configs[2]: 1-D, N=%d, IndexSetUniform(N, 4, 2): 5 resolutions, 31 partitions" % n
+        policy = "single root region (the reference's index set)"
+    else:
+        # root-block policy: the hierarchy starts at a layer whose blocks fit one device
+        # (first_divider_power=3 -> 8, 16, 32, 64, 128 regions); inputs in Hilbert order
+        n = args.n or 262144
+        res, d, power = 4, 2, 3
+        x, y, xs = workloads.make_chain_2d(n, q, order=ca.space_filling_order)
+        ells = workloads.chain_length_scales(res + 1, 2, ell0=0.7)
+        name = "BASELINE configs[3]: 2-D, N=%d, 5 resolutions of 8/16/32/64/128 partitions" % n
+        policy = "first_divider_power=3 (no single-region root: a 262144-point root would be a 512 GiB matrix); Hilbert-ordered inputs"
+    ns = xs.shape[0]
+    kernels = [ca.RBFKernel(l=l, sf=1.0, noise=0.01) for l in ells]
+    idx = ca.IndexSetUniform(n, res, 2, first_divider_power=power)
+    idx_t = ca.IndexSetUniform(ns, res, 2, first_divider_power=power)
+    group = td.group.WORLD if td.is_initialized() else None
+
+    def barrier():
+        if world > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    fits, preds, layer_ms = [], [], None
+    mean = var = None
+    owner = None
+    for it in range(args.warmup + args.steps):
+        barrier()
+        t0 = time.perf_counter()
+        model = ca.MultiResolutionGaussianProcess([x, y], index_set_obj=idx, spectral_density_obj=kernels, dtype=args.dtype,
+                                                  process_group=group, keep_factors=True)
+        model.fit()
+        barrier()
+        t1 = time.perf_counter()
+        mean, var = model.get_predicted_mean_and_var(xs, idx_t)
+        barrier()
+        t2 = time.perf_counter()
+        if it >= args.warmup:
+            fits.append(t1 - t0)
+            preds.append(t2 - t1)
+            layer_ms = model.layer_fit_ms()
+        owner = [o.tolist() for o in model.owner]
+        n_regions, n_samps = model.n_regions, model.n_samps
+        del model
+    fit_s, pred_s = float(np.median(fits)), float(np.median(preds))
+    if world > 1:                                   # the slowest rank's clock is the job's
+        t = torch.tensor([fit_s, pred_s], dtype=torch.float64, device="cuda")
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        fit_s, pred_s = float(t[0].item()), float(t[1].item())
+    nblocks = int(sum(n_regions))
+    if rank == 0:
+        out = {
+            "metric": "GP posteriors/sec, %s" % name,
+            "value": nblocks / (fit_s + pred_s),
+            "unit": "posteriors/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": (fit_s + pred_s) * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": name + ", q=2 outputs, N/4=%d test points, noise 0.01" % ns, "root_policy": policy,
+                       "regions_per_layer": n_regions, "block_sizes_per_layer": [sorted(set(v)) for v in n_samps],
+                       "blocks_per_rank": [[int(sum(1 for o in layer if o == r)) for layer in owner] for r in range(world)],
+                       "parallelism": "blocks sharded over ranks (LPT); 1 all-reduce per layer + 1 at prediction",
+                       "backend": (rehearsal or "nccl") if td.is_initialized() else "none"},
+            "fit_s": fit_s, "predict_s": pred_s, "layer_fit_ms": layer_ms,
+            "cholesky_flops": float(sum(sum(float(m) ** 3 / 3 for m in layer) for layer in n_samps)),
+            "mean_finite": bool(np.isfinite(mean).all()), "var_finite": bool(np.isfinite(var).all()),
+            "var_min": float(var.min()), "var_max": float(var.max()),
+            "peak_mem_GiB_rank0": torch.cuda.max_memory_allocated() / 2 ** 30,
+        }
+        out["cholesky_tflops_fit"] = out["cholesky_flops"] / fit_s / 1e12
+        if args.check or n <= 16384:
+            import oracle
+            xn, _, mu, sd = oracle.normalize_inputs(x)
+            specs = [oracle.DenseLayerSpec(l, 1.0, 0.01) for l in ells]
+            om, _ = oracle.mrgp_fit(xn, y, oracle.index_bounds_uniform(n, res, 2, power), specs)
+            omean, ovar = oracle.mrgp_predict(xn, om, specs, (xs - mu) / sd, oracle.index_bounds_uniform(ns, res, 2, power))
+            out.update(parity_fields(mean, var, omean, ovar))
+        print(json.dumps(out))
+        if out.get("parity_ok") is False:
+            raise SystemExit("bench.py --config %d: the GPU result differs from the oracle by more than 1e-5" % args.config)
+    if td.is_initialized():
+        td.destroy_process_group()
+    return 0
+
+
+def parity_fields(mean, var, omean, ovar):
+    """north_star: "1e-5 relative on predictive mean/variance".  Two readings are reported: relative to the
+    ARRAY's largest magnitude (max |err| / max |ref|, the bar of tests/) and ELEMENT-WISE for the variance
+    (max |err_i| / |ref_i|: the strict reading -- variances span orders of magnitude)."""
+    rec = {
+        "parity_rel_err_mean": float(np.max(np.abs(mean - omean)) / np.max(np.abs(omean))),
+        "parity_rel_err_var": float(np.max(np.abs(var - ovar)) / np.max(np.abs(ovar))),
+        "parity_rel_err_var_elementwise": float(np.max(np.abs(var - ovar) / np.abs(ovar))),
+        "oracle_var_min": float(np.min(ovar)),
+    }
+    rec["parity_ok"] = bool(rec["parity_rel_err_mean"] <= 1e-5 and rec["parity_rel_err_var"] <= 1e-5
+                            and rec["parity_rel_err_var_elementwise"] <= 1e-5)
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,7 +258,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-warmups", type=int, default=3)
     ap.add_argument("--cpu-repeats", type=int, default=5)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4],
+                    help="2: the headline N = 8192 block per GPU (default); 3 / 4: BASELINE configs[2] / [3], the "
+                         "multiresolution hierarchy with its blocks sharded over the ranks (--n scales it down)")
+    ap.add_argument("--check", action="store_true", help="--config 3/4: compare with the CPU oracle (done anyway for n <= 16384)")
+    ap.add_argument("--nccl-world1", action="store_true",
+                    help="one rank, backend nccl initialised, the step's reduce goes through RCCL unconditionally")
+    ap.add_argument("--rows-queues", type=int, default=0, choices=[0, 1, 2],
+                    help="queues for the carried rows (cimrgp_set_rows_queues); 0 = the default policy")
     args = ap.parse_args()
+    if args.config in (3, 4) and "--n" not in " ".join(sys.argv):
+        args.n = None
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
@@ -147,18 +281,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
+    # CIMRGP_BENCH_REHEARSAL=gloo: rehearse the N > 1 path on a box with ONE GPU (all ranks on
+    # cuda:0, gloo carrying the device tensors); the driver's multi-GPU runs use nccl = RCCL
+    rehearsal = os.environ.get("CIMRGP_BENCH_REHEARSAL", "")
+    if args.gpus > 1 or world > 1 or args.nccl_world1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        # CIMRGP_BENCH_REHEARSAL=gloo: rehearse the N > 1 path on a box with ONE GPU (all ranks on
-        # cuda:0, gloo carrying the device tensors); the driver's multi-GPU runs use nccl = RCCL
-        rehearsal = os.environ.get("CIMRGP_BENCH_REHEARSAL", "")
-        # More than one rank: keep every process within the runtime's 4 hardware queues (caller, panel
-        # chain, carried rows + the collective's stream).  With the carried rows' second queue a process
-        # has 5 streams: two such processes SHARING one GPU (the rehearsal) stall for over a second
-        # between steps (measured: 1581 against 22 ms per step), and with one process per GPU the fifth
-        # stream would share a hardware queue -- in order -- with one of the others.  Costs 2 % of a step.
-        os.environ.setdefault("CIMRGP_ROWS_ONE_QUEUE", "1")
         torch.cuda.set_device(0 if rehearsal else local_rank)
         if rehearsal:
             td.init_process_group(rehearsal, rank=rank, world_size=world)
@@ -167,6 +295,16 @@ def main():
             td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
+    # Queues for the carried rows.  Ranks SHARING one GPU (the rehearsal) must each stay within the runtime's four
+    # hardware queues -- caller, panel chain, carried rows, collective -- or the processes stall for hundreds of
+    # milliseconds between steps (1581 against 22 ms per step with a fifth stream); with one
+    # process per GPU the default (two rows queues) stays: --nccl-world1 measures that case with RCCL live.
+    if args.rows_queues:
+        _lib.set_rows_queues(args.rows_queues)
+    elif rehearsal and world > 1:
+        dist.share_one_gpu()
+    if args.config in (3, 4):
+        return run_config(args, world, rank, rehearsal)
     device = dev.require_gpu()
     tdt = dev.as_torch_dtype(args.dtype)
     lib = _lib.load()
@@ -210,7 +348,7 @@ def main():
         if timed:
             ev[4].record()
         fused[:q, rank * ns:(rank + 1) * ns] = mean.t()
-        dist.allreduce_sum_(fused)                                                  # the one collective
+        dist.allreduce_sum_(fused, force=args.nccl_world1)                          # the one collective
         if timed:
             ev[5].record()
 
@@ -275,7 +413,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 1-D, N=%d single-resolution single-partition RBF GP "
                                    "per GPU, q=2 outputs, N/4=%d test points, ell=0.1, sf2=1, noise=0.01" % (n, ns),
-                       "partitions_per_gpu": 1, "parallelism": "independent partitions, 1 all-reduce/step"},
+                       "partitions_per_gpu": 1, "parallelism": "independent partitions, 1 all-reduce/step",
+                       "backend": (rehearsal or "nccl") if td.is_initialized() else "none",
+                       "rows_queues": int(lib.cimrgp_get_rows_queues())},
             "cholesky_gflops": chol_gflops,
             "cholesky_frac_of_peak": chol_gflops / 1e3 / peak,
             "stage_ms": {"gram": stage_ms[0], "cross_gram_and_rhs_rows": stage_ms[1],
@@ -311,14 +451,12 @@ def main():
             # full-size parity of the headline config: the last timed step against the oracle's
             # posterior on the same arrays (north_star: 1e-5 relative on mean and variance, max
             # error over max magnitude as in tests/)
-            out["parity_rel_err_mean"] = float(np.max(np.abs(last_mean - omean)) / np.max(np.abs(omean)))
-            out["parity_rel_err_var"] = float(np.max(np.abs(last_var - ovar)) / np.max(np.abs(ovar)))
-            out["parity_ok"] = bool(out["parity_rel_err_mean"] <= 1e-5 and out["parity_rel_err_var"] <= 1e-5)
+            out.update(parity_fields(last_mean, last_var, omean, ovar))
         print(json.dumps(out))
         if out.get("parity_ok") is False:
             raise SystemExit("bench.py: the GPU posterior differs from the oracle by more than 1e-5: mean %.3e var %.3e"
                              % (out["parity_rel_err_mean"], out["parity_rel_err_var"]))
-    if world > 1:
+    if td.is_initialized():
         td.destroy_process_group()
 
 

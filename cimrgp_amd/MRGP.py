@@ -280,17 +280,20 @@ class MultiResolutionGaussianProcess(object):
                 owned = self._owned(j)
                 if not owned:
                     continue
-                # blocks of a layer write disjoint test ranges: in flight together on the stream
-                # pool; layers accumulate into the same ranges and follow one another
+                # blocks of a layer write disjoint test ranges: equal-sized ones in ONE batched call, the
+                # others in flight together on the stream pool; layers accumulate into the same ranges and
+                # follow one another
+                if want_var:
+                    self.posterior_obj[j].predict_layer(self._x_dev, xs, index_set.bounds[j], set(owned), mean, var,
+                                                        include_noise and last,
+                                                        lambda cnt, nmax: _Fanout(self.device, cnt, nmax))
+                    continue
                 fan = _Fanout(self.device, len(owned), max(self.n_samps[j][l] for l in owned))
                 for l in owned:
                     a, b = (int(v) for v in index_set.bounds[j][l])
                     blk = self.posterior_obj[j].blocks[l]
                     with torch.cuda.stream(fan.stream()):
-                        if want_var:
-                            blk.predict(xs[a:b], mean[a:b], var[a:b], add_noise=(include_noise and last))
-                        else:
-                            blk.predict(xs[a:b], mean[a:b], None)
+                        blk.predict(xs[a:b], mean[a:b], None)
                 fan.join()
         if self.world_size > 1:
             fused[:self.dy] = mean.t()

@@ -25,6 +25,8 @@ BATCH_MAX_N = int(os.environ.get("CIMRGP_BATCH_MAX_N", "16384"))
 # ---- independent blocks of one layer run concurrently (the reference's independent-over-l loop,
 # Posteriors.py:35-59): a small pool of streams per device; blocks are dealt round-robin.
 _POOLS = {}
+#: upper bound on the streams of the pool (dist.share_one_gpu sets 1: ranks sharing one GPU)
+MAX_BLOCK_STREAMS = 8
 
 
 def block_streams(device, n_blocks, n_max):
@@ -42,7 +44,7 @@ def block_streams(device, n_blocks, n_max):
         want = 2
     else:
         want = 1
-    want = max(1, min(want, n_blocks))
+    want = max(1, min(want, n_blocks, MAX_BLOCK_STREAMS))
     if want == 1:
         return []
     key = (torch.device(device).index, )
@@ -92,6 +94,8 @@ class DenseBlock(object):
         self.bias = None                 # (q,) device
         self.noise = None                # (1,) device
         self.r = None
+        self.batch = None                # _FittedBatch this block's factor lives in (or None)
+        self.batch_index = -1
 
     def fit(self, y, f_bar, train_out, shared_bias=None, shared_noise=None, keep_factor=True):
         """Fit on targets ``y - f_bar`` (both (n x q) device views); adds this
@@ -158,6 +162,30 @@ class DenseBlock(object):
         return -0.5 * r_dot_alpha - q * half_logdet - 0.5 * q * self.n * np.log(2 * np.pi)
 
 
+def _layer_array(views, group):
+    """The 2-D array (from the start of its storage) that the region views ``views[l]``, l in group, are row
+    ranges of; None if they are not slices of one row-major array."""
+    v0 = views[group[0]]
+    st = v0.untyped_storage().data_ptr()
+    rows = 0
+    for l in group:
+        v = views[l]
+        if v.untyped_storage().data_ptr() != st or v.stride() != v0.stride() or v.stride(1) != 1 \
+                or v.stride(0) != v.shape[1] or v.storage_offset() % v.stride(0) != 0:
+            return None
+        rows = max(rows, v.storage_offset() // v.stride(0) + v.shape[0])
+    return torch.as_strided(v0, (int(rows), int(v0.shape[1])), v0.stride(), 0)
+
+
+class _FittedBatch(object):
+    """Equal-sized blocks fitted together: their factors share one arena, so that a prediction can
+    address block i at ``base + i * stride`` (cimrgp_layer_predict)."""
+
+    def __init__(self, regions, n, starts, karena, ws_arena, z, bias, noise):
+        self.regions, self.n, self.starts = list(regions), int(n), starts
+        self.karena, self.ws_arena, self.z, self.bias, self.noise = karena, ws_arena, z, bias, noise
+
+
 class DensePosterior(object):
     """One resolution: a list of :class:`DenseBlock`, updated in place."""
 
@@ -168,6 +196,7 @@ class DensePosterior(object):
         self.noise_region_specific = noise_region_specific
         self.bias_region_specific = bias_region_specific
         self.blocks = [None] * self.n_regions
+        self.batches = []                # _FittedBatch records of the last sweep (equal-sized blocks fitted together)
 
     def update_scale_given_axis(self, y_mean, x, f_bar, train_out, owned=None, keep_factors=True):
         """``y_mean``, ``x``, ``f_bar``, ``train_out``: lists indexed by region of device
@@ -185,6 +214,7 @@ class DensePosterior(object):
             if not self.noise_region_specific and self.kernel.noise is None:
                 shared_noise = dev.noise_from_stats(stats, self.dy, NOISE_FRACTION, NOISE_FLOOR * self.kernel.sf)
         regions = list(regions)
+        self.batches = []
         if not regions:
             return
         # equal-sized small blocks: one batch per size (a uniform index set has at most two sizes per
@@ -194,7 +224,8 @@ class DensePosterior(object):
             by_size.setdefault(int(x[l].shape[0]), []).append(l)
         single = []
         for n_l, group in by_size.items():
-            if len(group) >= 2 and n_l <= BATCH_MAX_N:
+            sliced = all(_layer_array(v, group) is not None for v in (y_mean, x, f_bar, train_out))
+            if len(group) >= 2 and n_l <= BATCH_MAX_N and sliced:
                 self._fit_batched(group, y_mean, x, f_bar, train_out, shared_bias, shared_noise, keep_factors)
             else:
                 single.extend(group)
@@ -211,52 +242,99 @@ class DensePosterior(object):
         fan.join()
 
     def _fit_batched(self, group, y_mean, x, f_bar, train_out, shared_bias, shared_noise, keep_factors):
-        """Fit ``group`` (regions of equal size) with ONE batched factorisation and ONE batched
-        backward solve: the matrices live in one arena (batch x n x ld) and every kernel of the panel
-        sweep is launched once for all of them (cimrgp_potrf_rows_batched)."""
+        """Fit ``group`` (regions of equal size) with ONE C call per sub-batch (cimrgp_layer_fit): statistics,
+        residual rows, Gram matrices, the batched factorisation with the residual rows carried, the batched
+        backward solve and the training-point prediction are each launched once for all the blocks.  The
+        matrices live in one arena (batch x n x ld); a group whose arena would not fit the free memory is cut
+        into sub-batches (and the arena of a sub-batch is dropped at once when the factors are not kept)."""
         k = self.kernel
         n = int(x[group[0]].shape[0])
         q = self.dy
         device, dtype = y_mean[group[0]].device, y_mean[group[0]].dtype
-        nb = len(group)
         ld = dev.padded_ld(n)
-        karena = torch.empty((nb, n, ld), dtype=dtype, device=device)
-        ws_bytes = (dev.potrf_workspace_bytes(n, dtype) + 15) // 16 * 16
-        ws_arena = torch.empty((nb, max(ws_bytes, 16)), dtype=torch.uint8, device=device)
-        info = torch.zeros(nb, dtype=torch.int32, device=device)
-        ldq = dev.padded_ld(n)
-        rows = torch.empty((nb, q, ldq), dtype=dtype, device=device)
-        blocks, resid = [], []
-        for i, l in enumerate(group):
-            blk = DenseBlock(x[l], k)
-            stats = None
-            if shared_bias is None or (shared_noise is None and k.noise is None):
-                stats = dev.block_stats(y_mean[l], f_bar[l])
-            blk.bias = stats[:q] if shared_bias is None else shared_bias
-            if k.noise is not None:
-                blk.noise = torch.full((1,), k.noise, dtype=dtype, device=device)
-            elif shared_noise is not None:
-                blk.noise = shared_noise
-            else:
-                blk.noise = dev.noise_from_stats(stats, q, NOISE_FRACTION, NOISE_FLOOR * k.sf)
-            r = dev.residual(y_mean[l], f_bar[l], blk.bias)
-            dev.rbf_gram(blk.x, k.l, k.sf, 0.0, lower_only=True, out=karena[i])
-            dev.add_diag(karena[i], n, blk.noise)
-            blocks.append(blk)
-            resid.append(r)
-        rows[:, :, :n] = torch.stack(resid).transpose(1, 2)
-        # the targets ride through the factorisation as q extra rows per block: z = L^-1 r
-        dev.potrf_rows_batched(karena, n, ld, ws_arena, info, rows, q, ldq)
-        z = rows[:, :, :n].transpose(1, 2).contiguous()
-        alpha = dev.solve_lt_batched(karena, n, ld, ws_arena, z.clone())
-        for i, l in enumerate(group):
-            blk = blocks[i]
-            blk.info = info[i:i + 1]
-            blk.alpha = alpha[i]
-            if keep_factors:
-                blk.lbuf, blk.ws, blk.z = karena[i], ws_arena[i], z[i]
-            dev.train_mean(resid[i], blk.alpha, blk.bias, blk.noise, train_out[l], accumulate=True)
-            self.blocks[l] = blk
+        ws_bytes = max((dev.potrf_workspace_bytes(n, dtype) + 15) // 16 * 16, 16)
+        esz = torch.empty((), dtype=dtype).element_size()
+        per_block = n * ld * esz + ws_bytes + 6 * q * ld * esz
+        free_bytes = torch.cuda.mem_get_info(device)[0]
+        cached = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+        budget = (free_bytes + cached) * (0.8 if keep_factors else 0.4)
+        per_call = int(max(1, min(len(group), budget // per_block)))
+        # the layer's arrays: every region view is a slice of them (regions are contiguous ranges,
+        # Inputs.py:57-60), so a block is a row offset into them
+        y_all, x_all = _layer_array(y_mean, group), _layer_array(x, group)
+        f_all, t_all = _layer_array(f_bar, group), _layer_array(train_out, group)
+        def row_of(views, l):
+            return views[l].storage_offset() // views[l].stride(0)
+        for c0 in range(0, len(group), per_call):
+            sub = group[c0:c0 + per_call]
+            nb = len(sub)
+            karena = torch.empty((nb, n, ld), dtype=dtype, device=device)
+            ws_arena = torch.empty((nb, ws_bytes), dtype=torch.uint8, device=device)
+            info = torch.zeros(nb, dtype=torch.int32, device=device)
+            bias = torch.empty((nb, q), dtype=dtype, device=device)
+            noise = torch.empty(nb, dtype=dtype, device=device)
+            z = torch.empty((nb, n, q), dtype=dtype, device=device)
+            alpha = torch.empty((nb, n, q), dtype=dtype, device=device)
+            rows_y = [row_of(y_mean, l) for l in sub]
+            if any(row_of(v, l) != r for v in (x, f_bar, train_out) for l, r in zip(sub, rows_y)):
+                raise ValueError('the region views of a layer must be the same row ranges of x, y, f_bar and train_out')
+            starts = torch.tensor(rows_y, dtype=torch.int64).to(device, non_blocking=True)
+            dev.layer_fit(x_all, y_all, f_all, t_all, starts, n, k.l, k.sf, -1.0 if k.noise is None else float(k.noise),
+                          NOISE_FRACTION, NOISE_FLOOR * k.sf, shared_bias, shared_noise, karena, ws_arena, info, bias, noise,
+                          z, alpha)
+            batch = _FittedBatch(sub, n, starts, karena, ws_arena, z, bias, noise) if keep_factors else None
+            if batch is not None:
+                self.batches.append(batch)
+            for i, l in enumerate(sub):
+                blk = DenseBlock(x[l], k)
+                blk.info = info[i:i + 1]
+                blk.alpha = alpha[i]
+                blk.bias = bias[i]
+                blk.noise = noise[i:i + 1]
+                if keep_factors:
+                    blk.lbuf, blk.ws, blk.z = karena[i], ws_arena[i], z[i]
+                    blk.batch, blk.batch_index = batch, i
+                self.blocks[l] = blk
+
+    def predict_layer(self, x_all, xs, test_bounds, owned, mean, var, add_noise, fan_factory):
+        """Accumulate the layer's predictive mean and variance at the test points: test block l =
+        rows test_bounds[l] of ``xs``, served by training block l (MRGP.py:782-803).  Blocks that were fitted
+        together and have equally many test points go through ONE batched call per sub-batch
+        (cimrgp_layer_predict); the others one by one on the stream pool."""
+        done = set()
+        for bt in self.batches:
+            by_ns = {}
+            for i, l in enumerate(bt.regions):
+                if l in owned:
+                    a, b = (int(v) for v in test_bounds[l])
+                    by_ns.setdefault(b - a, []).append((i, a))
+            for ns, items in by_ns.items():
+                idx = [i for i, _ in items]
+                contiguous = idx == list(range(idx[0], idx[0] + len(idx)))
+                if ns <= 0 or len(items) < 2 or not contiguous:
+                    continue
+                ldw = dev.padded_ld(bt.n)
+                esz = xs.element_size()
+                free_bytes = torch.cuda.mem_get_info(xs.device)[0] + torch.cuda.memory_reserved(xs.device) \
+                    - torch.cuda.memory_allocated(xs.device)
+                per_call = int(max(1, min(len(items), (0.5 * free_bytes) // max(1, ns * ldw * esz))))
+                for c0 in range(0, len(items), per_call):
+                    part = items[c0:c0 + per_call]
+                    i0, nb = part[0][0], len(part)
+                    t_starts = torch.tensor([a for _, a in part], dtype=torch.int64).to(xs.device, non_blocking=True)
+                    dev.layer_predict(x_all, bt.starts[i0:i0 + nb], bt.n, xs, t_starts, ns, self.kernel.l, self.kernel.sf,
+                                      bt.karena[i0:i0 + nb], bt.ws_arena[i0:i0 + nb], bt.z[i0:i0 + nb], bt.bias[i0:i0 + nb],
+                                      bt.noise[i0:i0 + nb] if add_noise else None, mean, var)
+                done.update(bt.regions[i] for i, _ in items)
+        rest = [l for l in owned if l not in done]
+        if not rest:
+            return
+        fan = fan_factory(len(rest), max(self.blocks[l].n for l in rest))
+        for l in rest:
+            a, b = (int(v) for v in test_bounds[l])
+            with torch.cuda.stream(fan.stream()):
+                self.blocks[l].predict(xs[a:b], mean[a:b], var[a:b], add_noise=add_noise)
+        fan.join()
 
     @staticmethod
     def _whole_layer(views):

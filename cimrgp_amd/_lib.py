@@ -3,6 +3,7 @@
 The product path has no CPU fallback: if the HIP library is missing or a call
 fails, an exception is raised -- never a silent NumPy substitute.
 """
+import atexit
 import ctypes as C
 import os
 
@@ -45,6 +46,14 @@ SIGNATURES = {
     "cimrgp_basis_moments_scratch_bytes": (_sz, [_i64, _i32, _i32]),
     "cimrgp_basis_moments": (_i32, [_i32, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "cimrgp_basis_apply": (_i32, [_i32, _vp, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _dbl, _vp, _vp, _i32, _vp]),
+    "cimrgp_layer_fit": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _dbl, _dbl, _dbl, _dbl, _dbl, _vp, _vp,
+                                _vp, _i64, _i64, _vp, _sz, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cimrgp_layer_predict": (_i32, [_i32, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _dbl, _dbl, _vp, _i64, _i64, _vp, _sz,
+                                    _vp, _i32, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "cimrgp_set_rows_queues": (_i32, [_i32]),
+    "cimrgp_get_rows_queues": (_i32, []),
+    "cimrgp_tuning_build": (_i32, []),
+    "cimrgp_shutdown": (_i32, []),
     "cimrgp_profile_begin": (_i32, []),
     "cimrgp_profile_collect": (_i32, [C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_i64)]),
 }
@@ -67,19 +76,30 @@ def load():
             "`python -c 'import __graft_entry__ as g; g.build()'` or "
             "`bash cimrgp_amd/csrc/build.sh` (needs hipcc, --offload-arch=gfx950). "
             "There is no CPU fallback." % LIB_PATH)
-    if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1:
-        # One process of several (torch.distributed launchers export WORLD_SIZE): keep this process within
-        # the runtime's 4 hardware queues -- caller, panel chain, carried rows and the collective's stream.
-        # The factorisation's second carried-rows queue would be a fifth stream; the
-        # library reads the switch at its first factorisation.
-        os.environ.setdefault("CIMRGP_ROWS_ONE_QUEUE", "1")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if a symbol is missing
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    # The factorisations keep streams and events per caller stream and device; release them before the
+    # HIP runtime's own exit handlers run (cimrgp_shutdown in include/cimrgp.h).
+    atexit.register(_shutdown)
     return lib
+
+
+def _shutdown():
+    if _lib is not None:
+        try:
+            _lib.cimrgp_shutdown()
+        except Exception:
+            pass
+
+
+def set_rows_queues(queues):
+    """1 or 2 low-priority queues for the carried rows of ``cimrgp_potrf_rows`` (include/cimrgp.h):
+    1 keeps a process within four streams (caller, panel chain, rows, collective)."""
+    check(load().cimrgp_set_rows_queues(int(queues)), "cimrgp_set_rows_queues")
 
 
 def last_error():

@@ -2,6 +2,8 @@
 #include "common.hpp"
 
 #include <string.h>
+#include <stdlib.h>
+#include <atomic>
 
 namespace cimrgp {
 
@@ -22,6 +24,32 @@ int check_hip(hipError_t e, const char* fn, const char* what)
     return -2;
 }
 
+// ---- knobs (common.hpp) ----
+const Knobs& knobs()
+{
+    static const Knobs k = [] {
+        Knobs v;
+#ifdef CIMRGP_TUNING
+        auto num = [](const char* name, int64_t dflt) { const char* e = getenv(name); return e ? (int64_t)atoll(e) : dflt; };
+        const char* c = getenv("CIMRGP_CHAIN");
+        v.chain_mode = !c ? 0 : (c[0] == 's' ? 1 : c[0] == 'w' ? 2 : c[0] == 'q' ? 3 : 0);
+        v.tail_below = num("CIMRGP_TAIL_BELOW", v.tail_below);
+        v.rows_start_below = num("CIMRGP_ROWS_START", v.rows_start_below);
+        v.head_first_above = num("CIMRGP_HEAD_FIRST", v.head_first_above);
+        v.far_pair_above = num("CIMRGP_FAR_PAIR", v.far_pair_above);
+        v.fused_head0 = (int)num("CIMRGP_HEAD0", v.fused_head0);
+        v.gemm_pers = (int)num("CIMRGP_GEMM_PERS", v.gemm_pers);
+        v.pers_min_tiles = (int)num("CIMRGP_PERS_MIN_TILES", v.pers_min_tiles);
+        v.chain_cus = (int)num("CIMRGP_CHAIN_CUS", v.chain_cus);
+#endif
+        return v;
+    }();
+    return k;
+}
+
+static std::atomic<int> g_rows_queues{2};
+int rows_queues() { return g_rows_queues.load(std::memory_order_relaxed); }
+
 }  // namespace cimrgp
 
 using namespace cimrgp;
@@ -36,6 +64,38 @@ using namespace cimrgp;
 static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline size_t esize(int dtype) { return dtype == CIMRGP_F64 ? 8 : 4; }
 static inline bool ld_ok(int dtype, int64_t ld) { return ld % (dtype == CIMRGP_F64 ? 2 : 4) == 0; }
+
+template <typename T>
+static int layer_fit_typed(const void* x, const void* y, const void* fbar, void* train_out, const int64_t* starts, int batch,
+                           int64_t n, int d, int q, double ell, double sf2, double noise_fixed, double noise_frac,
+                           double noise_floor, const void* shared_bias, const void* shared_noise, void* k, int64_t ldk,
+                           int64_t k_stride, void* ws, size_t ws_stride_bytes, int32_t* info, void* rows, int64_t ldr, void* z,
+                           void* alpha, void* bias, void* noise, void* scratch, hipStream_t st)
+{
+    LayerFit<T> a;
+    a.x = (const T*)x; a.y = (const T*)y; a.fbar = (const T*)fbar; a.train_out = (T*)train_out; a.starts = starts;
+    a.batch = batch; a.n = n; a.d = d; a.q = q;
+    a.ell = ell; a.sf2 = sf2; a.noise_fixed = noise_fixed; a.noise_frac = noise_frac; a.noise_floor = noise_floor;
+    a.shared_bias = (const T*)shared_bias; a.shared_noise = (const T*)shared_noise;
+    a.k = (T*)k; a.ldk = ldk; a.sk = k_stride; a.ws = (T*)ws; a.sws = (int64_t)(ws_stride_bytes / sizeof(T)); a.info = info;
+    a.rows = (T*)rows; a.ldr = ldr; a.srows = (int64_t)q * ldr;
+    a.z = (T*)z; a.alpha = (T*)alpha; a.bias = (T*)bias; a.noise = (T*)noise; a.scratch = (T*)scratch;
+    return layer_fit_run<T>(a, st);
+}
+
+template <typename T>
+static int layer_predict_typed(const void* x, const int64_t* starts, int64_t n, int d, const void* xs, const int64_t* t_starts,
+                               int64_t ns, int batch, double ell, double sf2, const void* l, int64_t ldl, int64_t l_stride,
+                               const void* ws, size_t ws_stride_bytes, const void* z, int q, const void* bias, const void* noise,
+                               void* w, int64_t ldw, int64_t w_stride, void* mean, void* var, hipStream_t st)
+{
+    LayerPredict<T> a;
+    a.x = (const T*)x; a.starts = starts; a.n = n; a.d = d; a.xs = (const T*)xs; a.t_starts = t_starts; a.ns = ns; a.batch = batch;
+    a.ell = ell; a.sf2 = sf2; a.l = (const T*)l; a.ldl = ldl; a.sl = l_stride; a.ws = (const T*)ws;
+    a.sws = (int64_t)(ws_stride_bytes / sizeof(T)); a.z = (const T*)z; a.q = q; a.bias = (const T*)bias; a.noise = (const T*)noise;
+    a.w = (T*)w; a.ldw = ldw; a.sw = w_stride; a.mean = (T*)mean; a.var = (T*)var;
+    return layer_predict_run<T>(a, st);
+}
 
 extern "C" {
 
@@ -382,6 +442,80 @@ int cimrgp_basis_apply(int dtype, const void* x_dev, int64_t n, int d, const dou
                                     (float*)mean_dev, (float*)var_dev, accumulate, S(stream)),
              basis_apply_run<double>((const double*)x_dev, n, d, interval_dev, m, eau_dev, q, bias_dev, c2_dev, bias_var,
                                      (double*)mean_dev, (double*)var_dev, accumulate, S(stream)));
+}
+
+int cimrgp_layer_fit(int dtype, const void* x_dev, const void* y_dev, const void* fbar_dev, void* train_out_dev,
+                     const int64_t* starts_dev, int batch, int64_t n, int d, int q, double ell, double sf2, double noise_fixed,
+                     double noise_frac, double noise_floor, const void* shared_bias_dev, const void* shared_noise_dev,
+                     void* k_arena_dev, int64_t ldk, int64_t k_stride, void* ws_arena_dev, size_t ws_stride_bytes,
+                     int32_t* info_dev, void* rows_arena_dev, int64_t ldr, void* z_dev, void* alpha_dev, void* bias_dev,
+                     void* noise_dev, void* scratch_dev, void* stream)
+{
+    const char* fn = "cimrgp_layer_fit";
+    CIMRGP_REQUIRE(x_dev && y_dev && train_out_dev && starts_dev && k_arena_dev && ws_arena_dev && info_dev && rows_arena_dev &&
+                   z_dev && alpha_dev && bias_dev && noise_dev && scratch_dev, fn, "null pointer");
+    CIMRGP_REQUIRE(dtype == CIMRGP_F32 || dtype == CIMRGP_F64, fn, "unknown dtype");
+    CIMRGP_REQUIRE(batch >= 1 && n >= 1 && ldk >= n && ldr >= n, fn, "bad dimensions");
+    CIMRGP_REQUIRE(ld_ok(dtype, ldk) && ld_ok(dtype, ldr) && ld_ok(dtype, k_stride), fn, "leading dimensions and strides must be multiples of 16 bytes");
+    CIMRGP_REQUIRE(k_stride >= n * ldk - (ldk - n), fn, "matrix stride too small");
+    CIMRGP_REQUIRE(aligned16(k_arena_dev) && aligned16(ws_arena_dev) && aligned16(rows_arena_dev), fn, "pointers must be 16-byte aligned");
+    CIMRGP_REQUIRE(ws_stride_bytes >= cimrgp_potrf_workspace_bytes(dtype, n) && ws_stride_bytes % 16 == 0, fn,
+                   "workspace stride too small or misaligned");
+    CIMRGP_REQUIRE(ell > 0.0 && sf2 > 0.0, fn, "kernel parameters must be positive");
+    DISPATCH(dtype, fn,
+             layer_fit_typed<float>(x_dev, y_dev, fbar_dev, train_out_dev, starts_dev, batch, n, d, q, ell, sf2, noise_fixed,
+                                    noise_frac, noise_floor, shared_bias_dev, shared_noise_dev, k_arena_dev, ldk, k_stride,
+                                    ws_arena_dev, ws_stride_bytes, info_dev, rows_arena_dev, ldr, z_dev, alpha_dev, bias_dev,
+                                    noise_dev, scratch_dev, S(stream)),
+             layer_fit_typed<double>(x_dev, y_dev, fbar_dev, train_out_dev, starts_dev, batch, n, d, q, ell, sf2, noise_fixed,
+                                     noise_frac, noise_floor, shared_bias_dev, shared_noise_dev, k_arena_dev, ldk, k_stride,
+                                     ws_arena_dev, ws_stride_bytes, info_dev, rows_arena_dev, ldr, z_dev, alpha_dev, bias_dev,
+                                     noise_dev, scratch_dev, S(stream)));
+}
+
+int cimrgp_layer_predict(int dtype, const void* x_dev, const int64_t* starts_dev, int64_t n, int d, const void* xs_dev,
+                         const int64_t* t_starts_dev, int64_t ns, int batch, double ell, double sf2, const void* l_arena_dev,
+                         int64_t ldl, int64_t l_stride, const void* ws_arena_dev, size_t ws_stride_bytes, const void* z_dev, int q,
+                         const void* bias_dev, const void* noise_dev, void* w_arena_dev, int64_t ldw, int64_t w_stride,
+                         void* mean_dev, void* var_dev, void* stream)
+{
+    const char* fn = "cimrgp_layer_predict";
+    CIMRGP_REQUIRE(x_dev && starts_dev && xs_dev && t_starts_dev && l_arena_dev && ws_arena_dev && z_dev && w_arena_dev &&
+                   mean_dev && var_dev, fn, "null pointer");
+    CIMRGP_REQUIRE(dtype == CIMRGP_F32 || dtype == CIMRGP_F64, fn, "unknown dtype");
+    CIMRGP_REQUIRE(batch >= 1 && n >= 0 && ns >= 0 && ldl >= n && ldw >= n, fn, "bad dimensions");
+    CIMRGP_REQUIRE(ld_ok(dtype, ldl) && ld_ok(dtype, ldw) && ld_ok(dtype, l_stride) && ld_ok(dtype, w_stride), fn,
+                   "leading dimensions and strides must be multiples of 16 bytes");
+    CIMRGP_REQUIRE(w_stride >= ns * ldw - (ldw - n), fn, "W stride too small");
+    CIMRGP_REQUIRE(aligned16(l_arena_dev) && aligned16(ws_arena_dev) && aligned16(w_arena_dev), fn, "pointers must be 16-byte aligned");
+    CIMRGP_REQUIRE(ws_stride_bytes >= cimrgp_potrf_workspace_bytes(dtype, n), fn, "workspace stride too small");
+    DISPATCH(dtype, fn,
+             layer_predict_typed<float>(x_dev, starts_dev, n, d, xs_dev, t_starts_dev, ns, batch, ell, sf2, l_arena_dev, ldl,
+                                        l_stride, ws_arena_dev, ws_stride_bytes, z_dev, q, bias_dev, noise_dev, w_arena_dev, ldw,
+                                        w_stride, mean_dev, var_dev, S(stream)),
+             layer_predict_typed<double>(x_dev, starts_dev, n, d, xs_dev, t_starts_dev, ns, batch, ell, sf2, l_arena_dev, ldl,
+                                         l_stride, ws_arena_dev, ws_stride_bytes, z_dev, q, bias_dev, noise_dev, w_arena_dev, ldw,
+                                         w_stride, mean_dev, var_dev, S(stream)));
+}
+
+int cimrgp_set_rows_queues(int queues)
+{
+    if (queues != 1 && queues != 2) return fail("cimrgp_set_rows_queues", "queues must be 1 or 2");
+    g_rows_queues.store(queues, std::memory_order_relaxed);
+    return 0;
+}
+
+int cimrgp_get_rows_queues(void) { return rows_queues(); }
+
+int cimrgp_shutdown(void) { return potrf_shutdown(); }
+
+int cimrgp_tuning_build(void)
+{
+#ifdef CIMRGP_TUNING
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 int cimrgp_profile_begin(void) { return profile_begin(); }

@@ -100,6 +100,26 @@ template <> __device__ __forceinline__ uint4 neg_chunk<float>(uint4 v)
     return v;
 }
 
+// ---------------------------------------------------------------- knobs ----
+// Thresholds of the factorisation's schedule.  In the product build these are the constants below and
+// nothing reads the environment.  Built with -DCIMRGP_TUNING (tools/build_tuning.sh: the measurement
+// builds behind profiles/ and tools/sweep_*.sh) each CIMRGP_* environment variable named here overrides
+// its default once, at the first use.
+struct Knobs {
+    int chain_mode = 0;                    // CIMRGP_CHAIN = split | wide | quad: 1 round-1 links / 2 nine-wave / 3 four-wave (0: by context)
+    int64_t tail_below = 4864;             // CIMRGP_TAIL_BELOW: trailing matrix at or below this: finish on one queue
+    int64_t rows_start_below = 4608;       // CIMRGP_ROWS_START: carried rows start once the trailing matrix is smaller
+    int64_t head_first_above = 1ll << 30;  // CIMRGP_HEAD_FIRST: bulk update waits for the head above this (off)
+    int64_t far_pair_above = 8192;         // CIMRGP_FAR_PAIR: far part updated once per group of panels above this
+    int fused_head0 = 1;                   // CIMRGP_HEAD0: first diagonal block of a panel takes its head update itself
+    int gemm_pers = 0;                     // CIMRGP_GEMM_PERS: persistent trailing update on at most this many compute units (0: off)
+    int pers_min_tiles = 512;              // CIMRGP_PERS_MIN_TILES: 128-tiles below which the tile-per-workgroup kernel is used
+    int chain_cus = 0;                     // CIMRGP_CHAIN_CUS: compute units the bulk update leaves to the panel chain (look-ahead phase)
+};
+const Knobs& knobs();
+// Queues for the carried rows of cimrgp_potrf_rows (1 or 2): cimrgp_set_rows_queues in include/cimrgp.h.
+int rows_queues();
+
 // --------------------------------------------------------- host launchers ----
 // potrf.hip
 template <typename T> int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m, int64_t ldb,
@@ -109,14 +129,16 @@ struct PotrfBatch { int count = 1; int64_t sk = 0, sws = 0, sb = 0; };
 template <typename T> int potrf_batched_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m, int64_t ldb,
                                             PotrfBatch bt, hipStream_t st);
 template <typename T> int solve_rows_run(const T* l, int64_t n, int64_t ld, const T* ws, T* b, int64_t m,
-                                         int64_t ldb, hipStream_t st);
+                                         int64_t ldb, hipStream_t st, PotrfBatch bt = PotrfBatch());
+int potrf_shutdown();     // destroys the look-ahead contexts (streams, events): cimrgp_shutdown
 int profile_begin();
 int profile_collect(double* total_ms, double* total_flops, int64_t* launches);
 // gemm_nt.hip
 // A batch of independent products in one launch (equal shapes; element strides between problems).
 // skip_first: the first 64 x 64 tile of a rectangular update is left alone (the chain has already
 // replaced it by its factor; only honoured when the launch uses 64-tiles: gemm_uses_tile64)
-struct GemmBatch { int count = 1; int64_t sc = 0, sa = 0, sb = 0; int skip_first = 0; };
+// pers: compute units for the persistent form of the update (-1: knobs().gemm_pers, 0: never)
+struct GemmBatch { int count = 1; int64_t sc = 0, sa = 0, sb = 0; int skip_first = 0; int pers = -1; };
 bool gemm_uses_tile64(int64_t m, int64_t n, bool lower, int count = 1);
 template <typename T> int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t ldb,
                                       int64_t m, int64_t n, int k, bool lower, hipStream_t st, GemmBatch bt = GemmBatch());
@@ -124,6 +146,9 @@ template <typename T> int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda
 // gram.hip
 template <typename T> int rbf_gram_run(const T* xa, int64_t na, const T* xb, int64_t nb, int d, double ell, double sf2,
                                        double diag_add, T* k, int64_t ld, bool symm, bool lower_only, hipStream_t st);
+template <typename T> int rbf_gram_batched_run(const T* xa, const int64_t* a_starts, int64_t na, const T* xb, const int64_t* b_starts,
+                                               int64_t nb, int d, double ell, double sf2, const T* diag_dev, T* k, int64_t ld,
+                                               int64_t kstride, int batch, bool symm, hipStream_t st);
 template <typename T> int predict_mean_run(const T* x, int64_t n, int d, const T* alpha, int q, const T* xs, int64_t ns,
                                            double ell, double sf2, const T* bias, T* mean, int accumulate, hipStream_t st);
 // solve.hip
@@ -131,7 +156,7 @@ template <typename T> int potrs_run(const T* l, int64_t n, int64_t ld, const T* 
                                     bool backward_only, hipStream_t st, PotrfBatch bt = PotrfBatch());
 template <typename T> int predict_from_w_run(const T* w, int64_t ns, int64_t n, int64_t ldw, const T* z, int q, double sf2,
                                              double extra, const T* extra_dev, const T* bias, T* mean, T* var, int accumulate,
-                                             hipStream_t st);
+                                             hipStream_t st, int batch = 1, const int64_t* t_starts = nullptr, int64_t sw = 0);
 // misc.hip
 template <typename T> int misc_block_stats(const T* y, const T* fbar, int64_t n, int q, T* stats, hipStream_t st);
 template <typename T> int misc_residual(const T* y, const T* fbar, const T* bias, int64_t n, int q, T* r, hipStream_t st);
@@ -143,6 +168,28 @@ template <typename T> int misc_logdet_half(const T* l, int64_t n, int64_t ld, do
 template <typename T> int lml_grad_run(const T* x, int64_t n, int d, const T* kinv, int64_t ld, const T* alpha, int q,
                                        double ell, double sf2, double noise, double* out3, double* scratch, hipStream_t st,
                                        bool ard = false);
+
+// layer.hip: one call per layer for a batch of equal-sized blocks (strides in elements)
+template <typename T> struct LayerFit {
+    const T* x; const T* y; const T* fbar; T* train_out; const int64_t* starts;
+    int batch; int64_t n; int d; int q;
+    double ell, sf2, noise_fixed, noise_frac, noise_floor;
+    const T* shared_bias; const T* shared_noise;
+    T* k; int64_t ldk, sk; T* ws; int64_t sws; int32_t* info;
+    T* rows; int64_t ldr, srows;
+    T* z; T* alpha; T* bias; T* noise; T* scratch;
+};
+template <typename T> int layer_fit_run(const LayerFit<T>& a, hipStream_t st);
+template <typename T> struct LayerPredict {
+    const T* x; const int64_t* starts; int64_t n; int d;
+    const T* xs; const int64_t* t_starts; int64_t ns; int batch;
+    double ell, sf2;
+    const T* l; int64_t ldl, sl; const T* ws; int64_t sws;
+    const T* z; int q; const T* bias; const T* noise;
+    T* w; int64_t ldw, sw;
+    T* mean; T* var;
+};
+template <typename T> int layer_predict_run(const LayerPredict<T>& a, hipStream_t st);
 
 // reduced.hip
 template <typename T> int laplace_basis_run(const T* x, int64_t n, int d, const double* interval, int m, T* phi, hipStream_t st);

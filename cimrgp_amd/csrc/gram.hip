@@ -17,10 +17,9 @@ constexpr int MAXD  = 8;
 // D = compile-time input dimension (1, 2) or 0 = run-time d <= 8 with fully
 // unrolled, predicated loops (run-time indexed register arrays would spill).
 template <typename T, bool SYMM, int D>
-__global__ __launch_bounds__(256)
-void k_rbf_gram(const T* __restrict__ xa, int na, const T* __restrict__ xb, int nb, int d,
-                T neg_half_inv_l2, T sf2, T diag_add, T* __restrict__ K, int64_t ld,
-                int tiles_n, int lower_only)
+static __device__ __forceinline__ void gram_tile(const T* __restrict__ xa, int na, const T* __restrict__ xb, int nb, int d,
+                                                  T neg_half_inv_l2, T sf2, T diag_add, T* __restrict__ K, int64_t ld,
+                                                  int tiles_n, int lower_only)
 {
     __shared__ T sa[GTILE * MAXD];
     __shared__ T sb[GTILE * MAXD];
@@ -87,6 +86,31 @@ void k_rbf_gram(const T* __restrict__ xa, int na, const T* __restrict__ xb, int 
                 if (gc + b < nb) dst[b] = out[b];
         }
     }
+}
+
+template <typename T, bool SYMM, int D>
+__global__ __launch_bounds__(256)
+void k_rbf_gram(const T* __restrict__ xa, int na, const T* __restrict__ xb, int nb, int d,
+                T neg_half_inv_l2, T sf2, T diag_add, T* __restrict__ K, int64_t ld,
+                int tiles_n, int lower_only)
+{
+    gram_tile<T, SYMM, D>(xa, na, xb, nb, d, neg_half_inv_l2, sf2, diag_add, K, ld, tiles_n, lower_only);
+}
+
+// The blocks of one layer in one launch (blockIdx.y = block): block b takes its `na` rows of inputs at
+// row a_starts[b] of xa and its `nb` columns at row b_starts[b] of xb (regions are contiguous ranges of
+// the layer's arrays, Inputs.py:57-60), writes matrix b of the arena (stride kstride) and, on the
+// diagonal of a symmetric matrix, adds ITS noise (diag_dev[b]).
+template <typename T, bool SYMM, int D>
+__global__ __launch_bounds__(256)
+void k_rbf_gram_batched(const T* __restrict__ xa, const int64_t* __restrict__ a_starts, int na,
+                        const T* __restrict__ xb, const int64_t* __restrict__ b_starts, int nb, int d,
+                        T neg_half_inv_l2, T sf2, const T* __restrict__ diag_dev, T* __restrict__ K, int64_t ld,
+                        int64_t kstride, int tiles_n, int lower_only)
+{
+    const int b = blockIdx.y;
+    gram_tile<T, SYMM, D>(xa + a_starts[b] * d, na, xb + b_starts[b] * d, nb, d, neg_half_inv_l2, sf2,
+                          diag_dev ? diag_dev[b] : (T)0, K + (int64_t)b * kstride, ld, tiles_n, lower_only);
 }
 
 // D4: mean[i][c] (+)= bias[c] + sum_j k(xs_i, x_j) alpha[j][c].
@@ -181,6 +205,31 @@ int rbf_gram_run(const T* xa, int64_t na, const T* xb, int64_t nb, int d, double
 }
 
 template <typename T>
+int rbf_gram_batched_run(const T* xa, const int64_t* a_starts, int64_t na, const T* xb, const int64_t* b_starts, int64_t nb,
+                         int d, double ell, double sf2, const T* diag_dev, T* k, int64_t ld, int64_t kstride, int batch,
+                         bool symm, hipStream_t st)
+{
+    const char* fn = "cimrgp_layer";
+    if (na <= 0 || nb <= 0 || batch <= 0) return 0;
+    CIMRGP_REQUIRE(d >= 1 && d <= MAXD, fn, "input dimension must be in [1, 8]");
+    CIMRGP_REQUIRE(ell > 0.0, fn, "length-scale must be positive");
+    CIMRGP_REQUIRE(ld >= nb, fn, "leading dimension smaller than the number of columns");
+    CIMRGP_REQUIRE(na < (1ll << 30) && nb < (1ll << 30) && batch < 65536, fn, "batch too large");
+    const int64_t tm = (na + GTILE - 1) / GTILE, tn = (nb + GTILE - 1) / GTILE;
+    const int64_t tiles = symm ? tm * (tm + 1) / 2 : tm * tn;
+    CIMRGP_REQUIRE(tiles < (1ll << 31), fn, "grid too large");
+    const T c = (T)(-0.5 / (ell * ell));
+#define CIMRGP_GRAMB_LAUNCH(SYMM_, D_)                                                                      \
+    hipLaunchKernelGGL((k_rbf_gram_batched<T, SYMM_, D_>), dim3((unsigned)tiles, (unsigned)batch), dim3(256), 0, st, \
+                       xa, a_starts, (int)na, xb, b_starts, (int)nb, d, c, (T)sf2, diag_dev, k, ld, kstride, (int)tn, symm ? 1 : 0)
+    if (symm) { if (d == 1) CIMRGP_GRAMB_LAUNCH(true, 1); else if (d == 2) CIMRGP_GRAMB_LAUNCH(true, 2); else CIMRGP_GRAMB_LAUNCH(true, 0); }
+    else      { if (d == 1) CIMRGP_GRAMB_LAUNCH(false, 1); else if (d == 2) CIMRGP_GRAMB_LAUNCH(false, 2); else CIMRGP_GRAMB_LAUNCH(false, 0); }
+#undef CIMRGP_GRAMB_LAUNCH
+    CIMRGP_LAUNCH_CHECK(fn);
+    return 0;
+}
+
+template <typename T>
 int predict_mean_run(const T* x, int64_t n, int d, const T* alpha, int q, const T* xs, int64_t ns,
                      double ell, double sf2, const T* bias, T* mean, int accumulate, hipStream_t st)
 {
@@ -218,6 +267,10 @@ template int rbf_gram_run<double>(const double*, int64_t, const double*, int64_t
                                   double*, int64_t, bool, bool, hipStream_t);
 template int rbf_gram_run<float>(const float*, int64_t, const float*, int64_t, int, double, double, double,
                                  float*, int64_t, bool, bool, hipStream_t);
+template int rbf_gram_batched_run<double>(const double*, const int64_t*, int64_t, const double*, const int64_t*, int64_t, int,
+                                          double, double, const double*, double*, int64_t, int64_t, int, bool, hipStream_t);
+template int rbf_gram_batched_run<float>(const float*, const int64_t*, int64_t, const float*, const int64_t*, int64_t, int,
+                                         double, double, const float*, float*, int64_t, int64_t, int, bool, hipStream_t);
 template int predict_mean_run<double>(const double*, int64_t, int, const double*, int, const double*, int64_t,
                                       double, double, const double*, double*, int, hipStream_t);
 template int predict_mean_run<float>(const float*, int64_t, int, const float*, int, const float*, int64_t,

@@ -83,41 +83,10 @@ constexpr int SB = 64;   // diagonal sub-block
 // (thresholds 2048..6144) raises the update kernel's rate (49 -> 56 % of peak) but not the
 // end-to-end time (longer-lived update workgroups, longer slot waits of the chain), so it
 // starts above that size.
-constexpr int64_t FAR_PAIR_ABOVE = 8192;
-constexpr int64_t SINGLE_TAIL_BELOW = 4864;  // trailing matrix at or below this: finish on one queue (see potrf_run)
-constexpr int64_t HEAD_FIRST_ABOVE = 1 << 30;   // the bulk update would wait for the head update while the trailing matrix is larger: off (see potrf_run)
+constexpr int64_t FAR_PAIR_ABOVE = 8192;          // (= Knobs::far_pair_above; the carried rows' grouping uses the constant)
 constexpr int64_t ROWS_PAIR_ABOVE_SOLVE = 1024;   // stand-alone row-wise solve: pair the updates while more columns remain
-constexpr int64_t ROWS_START_BELOW = 4608;   // carried rows start once the trailing matrix is smaller than this
 
-// Measurement switches of the schedule, read once from the environment (defaults = the constants
-// above; tools/sweep_links.sh is the sweep they exist for).  Not part of the interface.
-//   CIMRGP_CHAIN = split | wide | quad   round 1's 4 x (k_diag64, k_trsm64) / nine-wave links
-//                                        everywhere / four-wave links everywhere (default: by context)
-//   CIMRGP_TAIL_BELOW, CIMRGP_ROWS_START, CIMRGP_HEAD_FIRST, CIMRGP_FAR_PAIR = rows   the four thresholds
-//   CIMRGP_ROWS_ONE_QUEUE                the carried rows' far updates on the rows' chain queue, and no second rows
-//                                        queue is created (for several processes SHARING one GPU: bench.py's rehearsal)
-//   CIMRGP_RESERVE_CUS = R               compute units per XCD kept free of the update kernels (make_ctx)
-struct Tuning {
-    int chain_mode = 0;                              // 0 by context, 1 split, 2 nine-wave links, 3 four-wave links
-    int64_t tail_below = SINGLE_TAIL_BELOW, rows_start_below = ROWS_START_BELOW;
-    int64_t head_first_above = HEAD_FIRST_ABOVE, far_pair_above = FAR_PAIR_ABOVE;
-    bool rows_two_queues = true;
-    bool fused_head0 = true;                         // CIMRGP_HEAD0=0: the first diagonal block of a panel waits for the head
-    Tuning()
-    {
-        auto num = [](const char* name, int64_t dflt) { const char* v = getenv(name); return v ? (int64_t)atoll(v) : dflt; };
-        const char* c = getenv("CIMRGP_CHAIN");
-        chain_mode = !c ? 0 : (c[0] == 's' ? 1 : c[0] == 'w' ? 2 : c[0] == 'q' ? 3 : 0);
-        tail_below = num("CIMRGP_TAIL_BELOW", SINGLE_TAIL_BELOW);
-        rows_start_below = num("CIMRGP_ROWS_START", ROWS_START_BELOW);
-        head_first_above = num("CIMRGP_HEAD_FIRST", HEAD_FIRST_ABOVE);
-        far_pair_above = num("CIMRGP_FAR_PAIR", FAR_PAIR_ABOVE);
-        rows_two_queues = (getenv("CIMRGP_ROWS_ONE_QUEUE") == nullptr);
-        fused_head0 = num("CIMRGP_HEAD0", 1) != 0;
-    }
-};
-static const Tuning& tuning() { static const Tuning t; return t; }
-
+// (the schedule's thresholds are `knobs()`, common.hpp: constants in the product build)
 
 // 16 bytes in flight between global memory and LDS.  A first-class vector: arrays of HIP's uint4
 // struct filled from global memory stay in scratch (the optimiser does not split the struct copy).
@@ -1259,8 +1228,11 @@ void k_linkq(T* __restrict__ A, int64_t ld, int n, int c0, int k0, int wn,
 template <typename T>
 __global__ __launch_bounds__(256)
 void k_trsm256(T* __restrict__ P, int64_t ldp, int M, int w, const T* __restrict__ Lpanel, int64_t ldl,
-               const T* __restrict__ inv64)
+               const T* __restrict__ inv64, int64_t sp = 0, int64_t sk = 0, int64_t sws = 0)
 {
+    P += (int64_t)blockIdx.y * sp;                   // batch: see k_diag64
+    Lpanel += (int64_t)blockIdx.y * sk;
+    inv64 += (int64_t)blockIdx.y * sws;
     const int row0 = (int)blockIdx.x * TR;
     const int mrows = min(TR, M - row0);
     __shared__ __attribute__((aligned(16))) unsigned char smem[TrsmLds<T>::BYTES];
@@ -1348,7 +1320,7 @@ static int panel_chain(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, int
                        T* b, int64_t m, int64_t ldb, PotrfBatch bt, hipStream_t st, const char* fn, bool alone,
                        bool first_done = false)
 {
-    const int chain_mode = tuning().chain_mode;
+    const int chain_mode = knobs().chain_mode;
     const bool split_links = (chain_mode == 1);
     // (a batch of factorisations in one launch is its own crowd: many link workgroups compete for the
     // compute units, and the four-wave form packs twice as many of them)
@@ -1408,13 +1380,15 @@ static int panel_chain(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, int
 // (adjacent panels are adjacent columns of B and of L).
 template <typename T>
 static int rows_panel_step(T* b, int64_t ldb, int64_t m, const T* lmat, int64_t ld, int64_t n, const T* ws,
-                           int64_t r0, PanelGroup& grp, int64_t pair_above, hipStream_t st, const char* fn)
+                           int64_t r0, PanelGroup& grp, int64_t pair_above, hipStream_t st, const char* fn,
+                           PotrfBatch bt = PotrfBatch())
 {
     const int64_t rw = (n - r0 < CIMRGP_NB) ? (n - r0) : CIMRGP_NB;
     const int64_t r1 = r0 + rw;
-    hipLaunchKernelGGL((k_trsm256<T>), dim3((unsigned)((m + TR - 1) / TR)), dim3(256), 0, st,
+    GemmBatch gb; gb.count = bt.count; gb.sc = gb.sa = bt.sb; gb.sb = bt.sk;
+    hipLaunchKernelGGL((k_trsm256<T>), dim3((unsigned)((m + TR - 1) / TR), (unsigned)bt.count), dim3(256), 0, st,
                        b + r0, ldb, (int)m, (int)rw, (const T*)(lmat + r0 * ld + r0), ld,
-                       (const T*)(ws + (r0 / SB) * (SB * SB)));
+                       (const T*)(ws + (r0 / SB) * (SB * SB)), bt.sb, bt.sk, bt.sws);
     CIMRGP_LAUNCH_CHECK(fn);
     if (n <= r1) { grp = PanelGroup(); return 0; }
     const int64_t rn = (n - r1 < CIMRGP_NB) ? (n - r1) : CIMRGP_NB;
@@ -1424,11 +1398,11 @@ static int rows_panel_step(T* b, int64_t ldb, int64_t m, const T* lmat, int64_t 
     }
     if (grp.g0 >= 0 && grp.left > 1 && n > r1 + rn) {
         --grp.left;
-        return gemm_nt_sub<T>(b + r1, ldb, b + grp.g0, ldb, lmat + r1 * ld + grp.g0, ld, m, rn, (int)(r1 - grp.g0), false, st);
+        return gemm_nt_sub<T>(b + r1, ldb, b + grp.g0, ldb, lmat + r1 * ld + grp.g0, ld, m, rn, (int)(r1 - grp.g0), false, st, gb);
     }
     const int64_t kk0 = (grp.g0 >= 0) ? grp.g0 : r0;
     grp = PanelGroup();
-    return gemm_nt_sub<T>(b + r1, ldb, b + kk0, ldb, lmat + r1 * ld + kk0, ld, m, n - r1, (int)(r1 - kk0), false, st);
+    return gemm_nt_sub<T>(b + r1, ldb, b + kk0, ldb, lmat + r1 * ld + kk0, ld, m, n - r1, (int)(r1 - kk0), false, st, gb);
 }
 
 template <typename T, bool FACTOR>
@@ -1442,7 +1416,7 @@ static int panel_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info,
         const int64_t w = (n - k0 < CIMRGP_NB) ? (n - k0) : CIMRGP_NB;
         const int64_t k1 = k0 + w;
         if (!FACTOR && rows) {
-            int rc = rows_panel_step<T>(b, ldb, m, kmat, ld, n, ws, k0, rows_grp, ROWS_PAIR_ABOVE_SOLVE, st, fn);
+            int rc = rows_panel_step<T>(b, ldb, m, kmat, ld, n, ws, k0, rows_grp, ROWS_PAIR_ABOVE_SOLVE, st, fn, bt);
             if (rc) return rc;
             continue;
         }
@@ -1487,8 +1461,8 @@ constexpr int64_t SINGLE_QUEUE_MAX = 5120;   // n at or below this: one queue, n
 
 struct LookAhead {
     hipStream_t side = nullptr;        // panel chain (high priority, all compute units)
-    hipStream_t bulk = nullptr;        // trailing updates: every compute unit but the reserved ones
-    hipStream_t rows = nullptr;        // carried rows: lags behind the factorisation; same mask as bulk
+    hipStream_t bulk = nullptr;        // trailing updates (unused: the caller's stream runs them)
+    hipStream_t rows = nullptr;        // carried rows: lags behind the factorisation
     hipStream_t rows_far = nullptr;    // carried rows: far part of each panel's update (beside the rows' own panel chain)
     std::vector<hipEvent_t> ev;
     hipStream_t owner = nullptr;       // the caller stream this context was created for
@@ -1505,28 +1479,14 @@ LookAhead* make_ctx(int dev)
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     bool ok = hipStreamCreateWithPriority(&la->side, hipStreamNonBlocking, hi) == hipSuccess;
-    // Optional (CIMRGP_RESERVE_CUS = R, default 0 = off): reserve R compute units of every XCD
-    // for the latency-bound chain by running the MFMA-bound update kernels on queues whose CU
-    // mask excludes them.  Mask bit b is CU b / 8 of XCD b % 8 (measured: a mask that thins out
-    // ONE XCD slows a kernel by that XCD's loss, because workgroups are dealt round-robin to
-    // the XCDs).  Measured and rejected as a default.  hipExtStreamCreateWithCUMask makes BLOCKING
-    // streams: with the caller on the legacy default stream (torch's default) they synchronise
-    // implicitly with everything the caller launches and slow the whole step (round 2, N = 8192:
-    // 95 -> 84 posteriors/s with R = 1).  With the caller on a non-blocking stream that cost is gone,
-    // and the gain is small (potrf 7.49 -> 7.38 ms, with 2050 carried rows 9.49 -> 9.36 ms at R = 2):
-    // the chain's wide links (panel solve, head update) need the whole machine and wait just the same.
-    const char* env = getenv("CIMRGP_RESERVE_CUS");
-    const int reserve = env ? atoi(env) : 0;
-    hipDeviceProp_t prop;
-    if (ok && reserve > 0 && reserve < 8 && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount == 256) {
-        uint32_t mask[8];
-        for (int wd = 0; wd < 8; ++wd) mask[wd] = 0xffffffffu;
-        for (int bit = 0; bit < 8 * reserve; ++bit) mask[bit >> 5] &= ~(1u << (bit & 31));
-        if (hipExtStreamCreateWithCUMask(&la->bulk, 8, mask) != hipSuccess) la->bulk = nullptr;
-        if (hipExtStreamCreateWithCUMask(&la->rows, 8, mask) != hipSuccess) la->rows = nullptr;
-    }
-    if (ok && la->rows == nullptr) ok = hipStreamCreateWithPriority(&la->rows, hipStreamNonBlocking, lo) == hipSuccess;
-    if (ok && tuning().rows_two_queues) ok = hipStreamCreateWithPriority(&la->rows_far, hipStreamNonBlocking, lo) == hipSuccess;
+    // (Round 2 could run the update kernels on CU-masked queues -- hipExtStreamCreateWithCUMask,
+    // CIMRGP_RESERVE_CUS -- to keep compute units free for the chain: measured useless three times
+    // (rejected (i)) and removed in round 3: masked streams are BLOCKING streams that
+    // synchronise with the legacy default stream, and they were the one kind of object still alive at
+    // process exit in the profiler runs that crashed in an exit handler.  The persistent update kernel
+    // splits the machine instead: a launch of G workgroups occupies G compute units.)
+    if (ok) ok = hipStreamCreateWithPriority(&la->rows, hipStreamNonBlocking, lo) == hipSuccess;
+    // (the carried rows' second queue is created on first use: ensure_rows_far)
     if (!ok) {
         if (la->side) (void)hipStreamDestroy(la->side);
         if (la->bulk) (void)hipStreamDestroy(la->bulk);
@@ -1560,6 +1520,28 @@ LookAhead* acquire_ctx(hipStream_t st)
     return list[(reinterpret_cast<uintptr_t>(st) >> 6) % MAX_CTX];
 }
 
+// Destroys every look-ahead context (streams, events) of every device.  The caller guarantees that no
+// factorisation is in flight or will be enqueued concurrently (cimrgp_shutdown).
+int destroy_contexts()
+{
+    std::lock_guard<std::mutex> guard(g_reg_mutex);
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    for (int dev = 0; dev < 16; ++dev) {
+        if (g_ctx[dev].empty()) continue;
+        (void)hipSetDevice(dev);
+        for (LookAhead* la : g_ctx[dev]) {
+            for (hipStream_t q : {la->side, la->bulk, la->rows, la->rows_far})
+                if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
+            for (hipEvent_t e : la->ev) (void)hipEventDestroy(e);
+            delete la;
+        }
+        g_ctx[dev].clear();
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return 0;
+}
+
 // Event pool of a context; call with la->enqueue held.
 bool grow_events(LookAhead* la, size_t nevents)
 {
@@ -1578,6 +1560,19 @@ int factor_panel(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, int64_t k
     return panel_chain<T>(kmat, n, ld, ws, info, k0, w, (T*)nullptr, 0, 0, PotrfBatch(), st, "cimrgp_potrf", alone, first_done);
 }
 }  // namespace
+
+int potrf_shutdown()
+{
+    {
+        std::lock_guard<std::mutex> guard(g_profile_mutex);
+        for (auto& r : g_recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
+        for (auto& r : g_free) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
+        g_recs.clear();
+        g_free.clear();
+        g_profile = false;
+    }
+    return destroy_contexts();
+}
 
 // Workspace layout: [ceil(n/64) slabs of 64x64 inverses][ceil(n/256) blocks of 256x256 invT].
 template <typename T>
@@ -1641,8 +1636,14 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     PanelGroup grp;                                    // open group of panels whose far update is still owed
     auto grp_open = [&]() { return grp.g0 >= 0; };
     bool tail_done = false;
-    const int64_t single_tail_below = tuning().tail_below;
+    const int64_t single_tail_below = knobs().tail_below;
     hipEvent_t ev_bulk_last = nullptr;                 // last thing queued on the bulk stream
+    // Bulk updates beside the chain: the persistent update kernel on all compute units but `chain_cus`,
+    // which stay free for the chain's kernels (one persistent workgroup fills a unit's registers, so the
+    // grid size IS the split).
+    GemmBatch bulk_gb;
+    if (knobs().gemm_pers > 0 && knobs().chain_cus > 0 && knobs().chain_cus < knobs().gemm_pers)
+        bulk_gb.pers = knobs().gemm_pers - knobs().chain_cus;
     int64_t rows_next = 0;                             // first panel the carried rows have not seen yet
     // Panel k0 is final (event ev_final): solve + update the carried rows.  They form their own
     // chain (panel p+1 of the rows needs panel p of the rows) that depends on the factorisation
@@ -1657,11 +1658,18 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     // start than 4608 trailing rows: 3072 / 5632 / 6656 / 8192 -> 89.2 / 94.3 / 91.6 / 89.5.)
     PanelGroup rows_grp;                               // carried rows: open group of panels whose far update is owed
     hipEvent_t ev_rows_far = nullptr;                  // carried rows: last far update queued on the second rows queue
-    const bool rows_pipeline = tuning().rows_two_queues;
+    // second rows queue: created when first wanted (cimrgp_set_rows_queues(1) before the first
+    // factorisation with carried rows means it never exists: a process then holds four streams)
+    if (rows && rows_queues() == 2 && la->rows_far == nullptr) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&la->rows_far, hipStreamNonBlocking, lo) != hipSuccess) la->rows_far = nullptr;
+    }
+    const bool rows_pipeline = (rows_queues() == 2) && la->rows_far != nullptr;
     auto rows_after_panel = [&](int64_t k0, int64_t k1, hipEvent_t ev_final) -> int {
         if (!rows) return 0;
         hipStream_t sq = la->rows;                     // always present (make_ctx: all queues or no context)
-        const int64_t rows_start_below = tuning().rows_start_below;
+        const int64_t rows_start_below = knobs().rows_start_below;
         const bool defer = (n - k1 > rows_start_below) && (k1 < n);
         if (defer) return 0;
         CIMRGP_HIP_TRY(hipStreamWaitEvent(sq, ev_final, 0), "hipStreamWaitEvent");
@@ -1756,7 +1764,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
             // of workgroups (55 us at N = 8192); the head then leaves that 64 x 64 tile alone.  Whole potrf,
             // without / with: N = 8192 6.54 / 6.47 ms, N = 16384 30.05 / 29.75; with carried rows it costs
             // (8.53 -> 8.82 ms with 2050 rows: the rows' queues then see an even busier chain), so not there.
-            const bool head0 = tuning().fused_head0 && !rows && tuning().chain_mode != 1 && w == CIMRGP_NB &&
+            const bool head0 = knobs().fused_head0 && !rows && knobs().chain_mode != 1 && w == CIMRGP_NB &&
                                gemm_uses_tile64(n - k1, wn, false);
             if (head0) {
                 const int sw0 = (int)((wn < SB) ? wn : SB);
@@ -1774,7 +1782,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
             // four-wave chain kernels the order no longer pays -- whole potrf, head first above 4608 rows
             // against never: N = 8192 6.72 against 6.56 ms, N = 16384 30.39 against 30.08 -- the switch
             // stays for measurements: CIMRGP_HEAD_FIRST = rows.)
-            const int64_t head_first_above = tuning().head_first_above;
+            const int64_t head_first_above = knobs().head_first_above;
             if (!rows && n - k1 > head_first_above) {
                 ev_go = la->ev[ne++];
                 CIMRGP_HIP_TRY(hipEventRecord(ev_go, sp), "hipEventRecord");
@@ -1795,7 +1803,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
                 const int64_t wnn = (n - k2 < CIMRGP_NB) ? (n - k2) : CIMRGP_NB;   // panel after next
                 const int64_t k3 = k2 + wnn;
                 if (grp.g0 < 0) {
-                    const int64_t far_pair_above = tuning().far_pair_above;
+                    const int64_t far_pair_above = knobs().far_pair_above;
                     const int g = group_size(n - k3, far_pair_above);
                     if (g > 1) { grp.g0 = k0; grp.left = g; }
                 }
@@ -1818,7 +1826,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
                             const double mm = (double)(n - k3);
                             hipEvent_t rec = rec_open(sb, mm * (mm + 1.0) * (double)kk);
                             rc = gemm_nt_sub<T>(k + k3 * ld + k3, ld, k + k3 * ld + grp.g0, ld, k + k3 * ld + grp.g0, ld,
-                                                n - k3, n - k3, kk, true, sb);
+                                                n - k3, n - k3, kk, true, sb, bulk_gb);
                             if (rec) (void)hipEventRecord(rec, sb);
                             if (rc) return rc;
                             ev_bulk_last = la->ev[ne++];
@@ -1830,7 +1838,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
                     const double mm = (double)(n - k2);
                     hipEvent_t rec = rec_open(sb, mm * (mm + 1.0) * (double)w);
                     rc = gemm_nt_sub<T>(k + k2 * ld + k2, ld, k + k2 * ld + k0, ld, k + k2 * ld + k0, ld,
-                                        n - k2, n - k2, (int)w, true, sb);
+                                        n - k2, n - k2, (int)w, true, sb, bulk_gb);
                     if (rec) (void)hipEventRecord(rec, sb);
                     if (rc) return rc;
                 }
@@ -1873,16 +1881,17 @@ int potrf_batched_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, i
 }
 
 template <typename T>
-int solve_rows_run(const T* l, int64_t n, int64_t ld, const T* ws, T* b, int64_t m, int64_t ldb, hipStream_t st)
+int solve_rows_run(const T* l, int64_t n, int64_t ld, const T* ws, T* b, int64_t m, int64_t ldb, hipStream_t st, PotrfBatch bt)
 {
-    return panel_sweep<T, false>(const_cast<T*>(l), n, ld, const_cast<T*>(ws), nullptr, b, m, ldb, st);
+    if (bt.count < 1 || bt.count >= 65536) return fail("cimrgp_trsm_rows", "batch count out of range");
+    return panel_sweep<T, false>(const_cast<T*>(l), n, ld, const_cast<T*>(ws), nullptr, b, m, ldb, st, bt);
 }
 
 template int potrf_run<double>(double*, int64_t, int64_t, double*, int32_t*, double*, int64_t, int64_t, hipStream_t);
 template int potrf_run<float>(float*, int64_t, int64_t, float*, int32_t*, float*, int64_t, int64_t, hipStream_t);
 template int potrf_batched_run<double>(double*, int64_t, int64_t, double*, int32_t*, double*, int64_t, int64_t, PotrfBatch, hipStream_t);
 template int potrf_batched_run<float>(float*, int64_t, int64_t, float*, int32_t*, float*, int64_t, int64_t, PotrfBatch, hipStream_t);
-template int solve_rows_run<double>(const double*, int64_t, int64_t, const double*, double*, int64_t, int64_t, hipStream_t);
-template int solve_rows_run<float>(const float*, int64_t, int64_t, const float*, float*, int64_t, int64_t, hipStream_t);
+template int solve_rows_run<double>(const double*, int64_t, int64_t, const double*, double*, int64_t, int64_t, hipStream_t, PotrfBatch);
+template int solve_rows_run<float>(const float*, int64_t, int64_t, const float*, float*, int64_t, int64_t, hipStream_t, PotrfBatch);
 
 }  // namespace cimrgp

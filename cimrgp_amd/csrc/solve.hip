@@ -229,8 +229,19 @@ template <typename T, int Q>
 __global__ __launch_bounds__(256)
 void k_predict_from_w(const T* __restrict__ W, int ns, int n, int64_t ldw, const T* __restrict__ z, int q,
                       T sf2_plus, const T* __restrict__ extra_dev, const T* __restrict__ bias, T* __restrict__ mean,
-                      T* __restrict__ var, int accumulate)
+                      T* __restrict__ var, int accumulate, const int64_t* __restrict__ t_starts = nullptr, int64_t sw = 0)
 {
+    if (t_starts) {
+        // the blocks of one layer in one launch (blockIdx.y = block): block b's rows of W are matrix b of the
+        // arena, its outputs start at test row t_starts[b]; z, bias and the extra variance are per block
+        const int b = blockIdx.y;
+        W += (int64_t)b * sw;
+        if (z) z += (int64_t)b * n * q;
+        if (bias) bias += (int64_t)b * q;
+        if (extra_dev) extra_dev += b;
+        if (mean) mean += t_starts[b] * q;
+        if (var) var += t_starts[b];
+    }
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= ns) return;
@@ -361,14 +372,17 @@ int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* 
 
 template <typename T>
 int predict_from_w_run(const T* w, int64_t ns, int64_t n, int64_t ldw, const T* z, int q, double sf2,
-                       double extra, const T* extra_dev, const T* bias, T* mean, T* var, int accumulate, hipStream_t st)
+                       double extra, const T* extra_dev, const T* bias, T* mean, T* var, int accumulate, hipStream_t st,
+                       int batch, const int64_t* t_starts, int64_t sw)
 {
     const char* fn = "cimrgp_predict_from_w";
-    if (ns <= 0) return 0;
+    if (ns <= 0 || batch <= 0) return 0;
     CIMRGP_REQUIRE(q >= 0 && q <= MAXQ, fn, "number of outputs must be <= 8");
-    CIMRGP_REQUIRE(ns < (1ll << 31) && n < (1ll << 31), fn, "too many points");
-    CIMRGP_Q_SWITCH(q > 0 ? q : 1, hipLaunchKernelGGL((k_predict_from_w<T, QQ>), dim3((unsigned)((ns + 3) / 4)), dim3(256), 0, st,
-                                                      w, (int)ns, (int)n, ldw, z, q, (T)(sf2 + extra), extra_dev, bias, mean, var, accumulate));
+    CIMRGP_REQUIRE(ns < (1ll << 31) && n < (1ll << 31) && batch < 65536, fn, "too many points");
+    CIMRGP_REQUIRE(batch == 1 || t_starts != nullptr, fn, "a batch needs the blocks' test offsets");
+    CIMRGP_Q_SWITCH(q > 0 ? q : 1, hipLaunchKernelGGL((k_predict_from_w<T, QQ>), dim3((unsigned)((ns + 3) / 4), (unsigned)batch), dim3(256), 0, st,
+                                                      w, (int)ns, (int)n, ldw, z, q, (T)(sf2 + extra), extra_dev, bias, mean, var, accumulate,
+                                                      t_starts, sw));
     CIMRGP_LAUNCH_CHECK(fn);
     return 0;
 }
@@ -376,8 +390,8 @@ int predict_from_w_run(const T* w, int64_t ns, int64_t n, int64_t ldw, const T* 
 template int potrs_run<double>(const double*, int64_t, int64_t, const double*, double*, int, double*, double*, bool, hipStream_t, PotrfBatch);
 template int potrs_run<float>(const float*, int64_t, int64_t, const float*, float*, int, float*, float*, bool, hipStream_t, PotrfBatch);
 template int predict_from_w_run<double>(const double*, int64_t, int64_t, int64_t, const double*, int, double, double,
-                                        const double*, const double*, double*, double*, int, hipStream_t);
+                                        const double*, const double*, double*, double*, int, hipStream_t, int, const int64_t*, int64_t);
 template int predict_from_w_run<float>(const float*, int64_t, int64_t, int64_t, const float*, int, double, double,
-                                       const float*, const float*, float*, float*, int, hipStream_t);
+                                       const float*, const float*, float*, float*, int, hipStream_t, int, const int64_t*, int64_t);
 
 }  // namespace cimrgp

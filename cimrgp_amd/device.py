@@ -144,6 +144,40 @@ def solve_lt_batched(karena, n, ld, ws_arena, z):
     return z
 
 
+def layer_fit(x, y, fbar, train_out, starts, n, ell, sf2, noise_fixed, noise_frac, noise_floor, shared_bias, shared_noise,
+              karena, ws_arena, info, bias, noise, z, alpha):
+    """The fit of ``batch`` equal-sized blocks of one layer in ONE call (cimrgp_layer_fit, include/cimrgp.h).
+    x, y, fbar, train_out: the LAYER's arrays (N x d / N x q); starts: device int64 (batch,) row offsets.
+    karena (batch, n, ld), ws_arena (batch, ws_bytes) uint8, info (batch,) int32, bias (batch, q), noise (batch,),
+    z / alpha (batch, n, q) are filled.  noise_fixed < 0: from the statistics (or ``shared_noise``)."""
+    lib = _lib.load()
+    batch = int(karena.shape[0])
+    q = int(y.shape[1])
+    d = int(x.shape[1])
+    ldr = padded_ld(n)
+    rows = torch.empty((batch, q, ldr), dtype=y.dtype, device=y.device)
+    scratch = torch.empty((batch, 2 * q * max(int(n), 1)), dtype=y.dtype, device=y.device)
+    _lib.check(lib.cimrgp_layer_fit(_DT[y.dtype], _p(x), _p(y), _p(fbar), _p(train_out), _p(starts), batch, int(n), d, q,
+                                    float(ell), float(sf2), float(noise_fixed), float(noise_frac), float(noise_floor),
+                                    _p(shared_bias), _p(shared_noise), _p(karena), karena.stride(1), karena.stride(0),
+                                    _p(ws_arena), ws_arena.stride(0), _p(info), _p(rows), ldr, _p(z), _p(alpha), _p(bias),
+                                    _p(noise), _p(scratch), _stream()), "cimrgp_layer_fit")
+
+
+def layer_predict(x, starts, n, xs, t_starts, ns, ell, sf2, larena, ws_arena, z, bias, noise, mean, var):
+    """Predictive mean and variance of ``batch`` equal-sized blocks at ``ns`` test points each in ONE call
+    (cimrgp_layer_predict): accumulates into mean (N* x q) / var (N*,) at rows t_starts[b] ...; ``noise``
+    (batch,) or None is added to the variance."""
+    lib = _lib.load()
+    batch = int(larena.shape[0])
+    ldw = padded_ld(n)
+    w = torch.empty((batch, max(int(ns), 1), ldw), dtype=x.dtype, device=x.device)
+    _lib.check(lib.cimrgp_layer_predict(_DT[x.dtype], _p(x), _p(starts), int(n), int(x.shape[1]), _p(xs), _p(t_starts), int(ns),
+                                        batch, float(ell), float(sf2), _p(larena), larena.stride(1), larena.stride(0),
+                                        _p(ws_arena), ws_arena.stride(0), _p(z), int(z.shape[2]), _p(bias), _p(noise),
+                                        _p(w), ldw, w.stride(0), _p(mean), _p(var), _stream()), "cimrgp_layer_predict")
+
+
 def solve_lt(lbuf, n, ws, z):
     """Backward half of D3: z (n x q) = L^-1 R is overwritten with alpha = L^-T z."""
     lib = _lib.load()

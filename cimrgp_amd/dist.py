@@ -39,12 +39,24 @@ def assign_blocks(sizes, world_size):
     return owner
 
 
-def allreduce_sum_(tensor, group=None):
-    """In-place sum over ranks; a no-op for a single process."""
+def allreduce_sum_(tensor, group=None, force=False):
+    """In-place sum over ranks; a no-op for a single process unless ``force`` (then a group of one is
+    reduced through its backend all the same: the only way to exercise RCCL on a one-GPU box)."""
     _, ws = world(group)
-    if ws > 1:
+    if ws > 1 or (force and td.is_available() and td.is_initialized()):
         td.all_reduce(tensor, op=td.ReduceOp.SUM, group=group)
     return tensor
+
+
+def share_one_gpu():
+    """Several ranks SHARE one GPU (rehearsals and the 2-rank tests on a one-GPU box; production runs one
+    process per GPU).  Each process must then stay within the runtime's four hardware queues: one queue for
+    the carried rows (cimrgp_set_rows_queues(1)), no stream pool for the independent blocks of a layer, one
+    look-ahead context.  Measured: two such processes with five or more streams each stall for hundreds of
+    milliseconds between steps."""
+    from . import _lib, Posteriors
+    _lib.set_rows_queues(1)
+    Posteriors.MAX_BLOCK_STREAMS = 1
 
 
 class RemoteRankError(RuntimeError):

@@ -235,6 +235,69 @@ int cimrgp_basis_apply(int dtype, const void* x_dev, int64_t n, int d,
                        const double* c2_dev, double bias_var, void* mean_dev,
                        void* var_dev, int accumulate, void* stream);
 
+/* ---- one call per layer: a batch of equal-sized blocks --------------------
+ * The reference loops over the regions l of a resolution in Python
+ * (src/Posteriors.py:35-59 for the fit, src/MRGP.py:782-803 for the
+ * prediction); regions are contiguous index ranges (src/Inputs.py:57-60), so
+ * block b of the batch is row offset starts_dev[b] (DEVICE array of int64) into
+ * the layer's arrays x (N x d), y (N x q), f_bar (N x q or NULL), train_out.
+ *
+ * cimrgp_layer_fit: for each of `batch` blocks of n points
+ *   bias_b  = shared_bias_dev (q values) if given, else the column means of y - f_bar
+ *   noise_b = noise_fixed if >= 0, else shared_noise_dev[0] if given, else
+ *             max(noise_frac * pooled variance about the column means, noise_floor)
+ *             (src/RegressionInput.py:62: labels.var() * 0.01)
+ *   K_b = sf2 exp(-|x - x'|^2 / (2 ell^2)) + noise_b I (lower) -> L_b L_b^T in place in
+ *   matrix b of k_arena_dev (leading dimension ldk, stride k_stride elements),
+ *   with the workspace of cimrgp_potrf at byte stride ws_stride_bytes, info_dev[b]
+ *   as cimrgp_potrf; z_b = L_b^-1 r_b (n x q), alpha_b = K_b^-1 r_b (n x q),
+ *   r_b = y - f_bar - bias_b; train_out[block rows] += K_noiseless alpha_b + bias_b.
+ *   rows_arena_dev (batch x q x ldr) and scratch_dev (batch x 2 q n elements) are
+ *   work areas; bias_dev (batch x q) and noise_dev (batch) receive the values used.
+ * cimrgp_layer_predict: for each block, at its ns test points (rows
+ *   t_starts_dev[b] .. + ns of xs (N* x d), mean (N* x q) and var (N*)):
+ *   W_b = K(xs_b, x_b) L_b^-T into matrix b of w_arena_dev (ns x ldw, stride
+ *   w_stride), mean += W_b z_b + bias_b, var += sf2 - sum W_b^2 (+ noise_dev[b] if
+ *   noise_dev is not NULL).  All blocks of a call share n and ns. */
+int cimrgp_layer_fit(int dtype, const void* x_dev, const void* y_dev, const void* fbar_dev,
+                     void* train_out_dev, const int64_t* starts_dev, int batch, int64_t n,
+                     int d, int q, double ell, double sf2, double noise_fixed,
+                     double noise_frac, double noise_floor, const void* shared_bias_dev,
+                     const void* shared_noise_dev, void* k_arena_dev, int64_t ldk,
+                     int64_t k_stride, void* ws_arena_dev, size_t ws_stride_bytes,
+                     int32_t* info_dev, void* rows_arena_dev, int64_t ldr, void* z_dev,
+                     void* alpha_dev, void* bias_dev, void* noise_dev, void* scratch_dev,
+                     void* stream);
+int cimrgp_layer_predict(int dtype, const void* x_dev, const int64_t* starts_dev, int64_t n,
+                         int d, const void* xs_dev, const int64_t* t_starts_dev, int64_t ns,
+                         int batch, double ell, double sf2, const void* l_arena_dev,
+                         int64_t ldl, int64_t l_stride, const void* ws_arena_dev,
+                         size_t ws_stride_bytes, const void* z_dev, int q,
+                         const void* bias_dev, const void* noise_dev, void* w_arena_dev,
+                         int64_t ldw, int64_t w_stride, void* mean_dev, void* var_dev,
+                         void* stream);
+
+/* ---- process-level policy (no reference counterpart: the reference is one
+ * process, src/MRGP.py has no streams) --------------------------------------
+ * cimrgp_set_rows_queues: how many low-priority queues cimrgp_potrf_rows may
+ * use for the carried rows (2 = default: the rows' own panel chain and their
+ * far updates side by side; 1 = one queue, for a process that must stay within
+ * four streams -- caller, panel chain, rows, collective -- e.g. one rank of
+ * several SHARING a GPU).  Takes effect for
+ * factorisations enqueued afterwards; returns 0, or <0 for a value other than
+ * 1 or 2.  cimrgp_get_rows_queues returns the current value.
+ * cimrgp_tuning_build: 1 when the library was compiled with -DCIMRGP_TUNING
+ * (schedule thresholds read from CIMRGP_* environment variables; tools/ only),
+ * 0 for the product build, which reads no environment variable.
+ * cimrgp_shutdown: destroys the streams and events the factorisations created
+ * (one look-ahead context per caller stream and device).  Call it when no call
+ * of this library is in flight, before the HIP runtime is torn down -- the
+ * Python loader registers it with atexit; later calls re-create what they need. */
+int cimrgp_set_rows_queues(int queues);
+int cimrgp_get_rows_queues(void);
+int cimrgp_tuning_build(void);
+int cimrgp_shutdown(void);
+
 /* ---- measurement hooks (bench.py roofline; no reference counterpart) ---------
  * Between begin and collect every lower-triangular trailing-update launch of
  * cimrgp_potrf is bracketed by HIP events on its own stream.  collect waits
