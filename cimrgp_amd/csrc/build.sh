@@ -7,7 +7,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 OBJS=()
 pids=()
 for f in api gemm_nt potrf gram solve misc reduced layer; do
-    if [ ! -f "$f.o" ] || [ "$f.hip" -nt "$f.o" ] || [ common.hpp -nt "$f.o" ] || [ ../../include/cimrgp.h -nt "$f.o" ]; then
+    if [ ! -f "$f.o" ] || [ "$f.hip" -nt "$f.o" ] || [ common.hpp -nt "$f.o" ] || [ gemm_tile.hpp -nt "$f.o" ] || [ ../../include/cimrgp.h -nt "$f.o" ]; then
         $HIPCC $FLAGS -c "$f.hip" -o "$f.o" &
         pids+=($!)
     fi

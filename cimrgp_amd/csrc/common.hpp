@@ -112,9 +112,9 @@ struct Knobs {
     int64_t head_first_above = 1ll << 30;  // CIMRGP_HEAD_FIRST: bulk update waits for the head above this (off)
     int64_t far_pair_above = 8192;         // CIMRGP_FAR_PAIR: far part updated once per group of panels above this
     int fused_head0 = 1;                   // CIMRGP_HEAD0: first diagonal block of a panel takes its head update itself
-    int gemm_pers = 0;                     // CIMRGP_GEMM_PERS: persistent trailing update on at most this many compute units (0: off)
+    int gemm_pers = 256;                   // CIMRGP_GEMM_PERS: persistent trailing update on at most this many compute units (0: off)
     int pers_min_tiles = 512;              // CIMRGP_PERS_MIN_TILES: 128-tiles below which the tile-per-workgroup kernel is used
-    int chain_cus = 0;                     // CIMRGP_CHAIN_CUS: compute units the bulk update leaves to the panel chain (look-ahead phase)
+    int chain_cus = 32;                    // CIMRGP_CHAIN_CUS: compute units the bulk update leaves to the panel chain (look-ahead phase)
 };
 const Knobs& knobs();
 // Queues for the carried rows of cimrgp_potrf_rows (1 or 2): cimrgp_set_rows_queues in include/cimrgp.h.

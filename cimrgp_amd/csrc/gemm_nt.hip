@@ -15,179 +15,11 @@
 // Algorithmic work: 2 M N K flop (M N K for the lower-triangular SYRK form),
 // bounded by the MFMA pipe.
 #include "common.hpp"
+#include "gemm_tile.hpp"
 
 namespace cimrgp {
 
 namespace {
-
-constexpr int KT_BYTES = 128;            // K bytes per row per stage
-constexpr int LROW     = KT_BYTES + 16;  // LDS row stride
-// W = MFMA tiles per wave and direction: W = 4 -> 128 x 128 workgroup tile (the trailing
-// update: 73,728 B of LDS, 2 workgroups per CU), W = 2 -> 64 x 64 tile (thin updates such as
-// the look-ahead "head", where a 128-tile grid would leave half of the CUs empty).
-
-// EDGE = false: M, N multiples of 128 and K a multiple of the stage depth -- no bounds logic
-// at all (every select on a prefetched register makes hipcc wait for it right behind the
-// load).  EDGE = true: ragged sizes, zero-fill and predicated stores.
-template <typename T, bool LOWER, bool EDGE, int W>
-static __device__ __forceinline__ void gemm_tile(unsigned char* smem, T* __restrict__ C, int64_t ldc,
-                                                  const T* __restrict__ A, int64_t lda,
-                                                  const T* __restrict__ B, int64_t ldb,
-                                                  int M, int N, int K, int ti, int tj)
-{
-    using X = Mx<T>;
-    using acc_t = typename X::acc_t;
-    constexpr int BKE = KT_BYTES / (int)sizeof(T);
-    constexpr int GT = 32 * W;               // tile edge
-    constexpr int NP = GT / 32;              // staging passes (32 rows each)
-    constexpr int OP_BYTES = GT * LROW;      // one operand, one stage
-    const int row0 = ti * GT, col0 = tj * GT;
-
-    const int tid  = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-
-    // global -> register staging map: 8 threads cover one 128-byte row segment
-    const int sc = tid & 7;
-    const int sr = tid >> 3;
-    const int nkt = (K + BKE - 1) / BKE;
-
-    // Staging addresses: uniform tile base (SGPRs) + one 32-bit per-thread element offset per
-    // operand row group, so the 8 loads of a stage need 8 VGPRs of addressing, not 16.
-    bool a_ok[NP], b_ok[NP];
-    int a_off_e[NP], b_off_e[NP];
-    const T* a_tile = A + (int64_t)row0 * lda;
-    const T* b_tile = B + (int64_t)col0 * ldb;
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const int r = sr + 32 * p;
-        a_ok[p] = (row0 + r) < M;
-        b_ok[p] = (col0 + r) < N;
-        a_off_e[p] = ((EDGE && !a_ok[p]) ? 0 : r) * (int)lda + sc * X::EPC;
-        b_off_e[p] = ((EDGE && !b_ok[p]) ? 0 : r) * (int)ldb + sc * X::EPC;
-    }
-
-    uint4 ra[NP], rb[NP];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
-
-    // GLOAD only ISSUES the loads (clamped, always valid addresses); every use of the loaded
-    // registers (zero-fill of out-of-range rows/columns) is in SWRITE, after the MFMA block,
-    // so the s_waitcnt lands there and the loads fly during the multiply.  The sign flip that
-    // turns the chain into C - A B^T is applied to the A fragments after the LDS read (one
-    // XOR per fragment and 16 MFMAs); flipping the staged registers component-wise makes
-    // hipcc shuffle them right behind the loads and wait there.
-#define CIMRGP_GLOAD(kt_)                                                        \
-    {                                                                            \
-        const int kcol = (kt_) * BKE + sc * X::EPC;                              \
-        const int koff = (!EDGE || kcol < K) ? (kt_) * BKE : 0;                  \
-        _Pragma("unroll") for (int p = 0; p < NP; ++p) {                         \
-            ra[p] = *reinterpret_cast<const uint4*>(a_tile + (a_off_e[p] + koff)); \
-            rb[p] = *reinterpret_cast<const uint4*>(b_tile + (b_off_e[p] + koff)); \
-        }                                                                        \
-    }
-#define CIMRGP_SWRITE(buf_, kt_)                                                 \
-    {                                                                            \
-        unsigned char* as_ = smem + (buf_) * 2 * OP_BYTES;                       \
-        unsigned char* bs_ = as_ + OP_BYTES;                                     \
-        const int kcol = (kt_) * BKE + sc * X::EPC;                              \
-        const bool kin = kcol < K;                                               \
-        const bool kfull = kcol + X::EPC <= K;                                   \
-        _Pragma("unroll") for (int p = 0; p < NP; ++p) {                         \
-            uint4 va = ra[p], vb = rb[p];                                        \
-            if (EDGE) {                                                          \
-                if (!(a_ok[p] && kin)) va = zero4;                               \
-                if (!(b_ok[p] && kin)) vb = zero4;                               \
-                if (!kfull) { va = mask_chunk<T>(va, kcol, K); vb = mask_chunk<T>(vb, kcol, K); } \
-            }                                                                    \
-            *reinterpret_cast<uint4*>(as_ + (sr + 32 * p) * LROW + sc * 16) = va; \
-            *reinterpret_cast<uint4*>(bs_ + (sr + 32 * p) * LROW + sc * 16) = vb; \
-        }                                                                        \
-    }
-
-    const int frow = lane & 15, fslot = lane >> 4;
-    const unsigned a_off = (unsigned)((wr * 16 * W + frow) * LROW + fslot * 8);
-    const unsigned b_off = (unsigned)((wc * 16 * W + frow) * LROW + fslot * 8);
-
-    STAMP(16);
-    CIMRGP_GLOAD(0);
-    // The accumulators start as the C tile and the A fragments are NEGATED, so the MFMA
-    // chain itself computes C - A B^T: the 64 C loads per lane are independent and in flight
-    // together with the first operand tiles, and the epilogue is stores only.  (A read-modify-
-    // write epilogue serialises 64 dependent load->store round trips per lane.)
-    const bool diag_tile = LOWER && (ti == tj);
-    acc_t acc[W][W];
-#pragma unroll
-    for (int mi = 0; mi < W; ++mi) {
-#pragma unroll
-        for (int ni = 0; ni < W; ++ni) {
-            const int gc = col0 + wc * 16 * W + ni * 16 + (lane & 15);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gr = row0 + wr * 16 * W + mi * 16 + X::crow(lane, r);
-                // unconditional load from a clamped (always valid) address, then select
-                if (EDGE) {
-                    const T v = C[(int64_t)min(gr, M - 1) * ldc + min(gc, N - 1)];
-                    acc[mi][ni][r] = (gr < M && gc < N && (!diag_tile || gc <= gr)) ? v : (T)0;
-                } else {
-                    acc[mi][ni][r] = C[(int64_t)gr * ldc + gc];     // junk above the diagonal is never stored
-                }
-            }
-        }
-    }
-    CIMRGP_SWRITE(0, 0);
-    // Make the C loads complete HERE: otherwise hipcc guards the first MFMA of every loop
-    // iteration with s_waitcnt vmcnt(0), which also drains the operand prefetch just issued.
-#pragma unroll
-    for (int mi = 0; mi < W; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < W; ++ni) asm volatile("" : "+v"(acc[mi][ni]));
-    __syncthreads();
-    STAMP(17);
-
-    for (int kt = 0; kt < nkt; ++kt) {
-        const bool more = (kt + 1) < nkt;
-        if (more) CIMRGP_GLOAD(kt + 1);
-        const unsigned char* as = smem + (kt & 1) * 2 * OP_BYTES;
-        const unsigned char* bs = as + OP_BYTES;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            uint2 a[W], b[W];
-#pragma unroll
-            for (int mi = 0; mi < W; ++mi)
-                a[mi] = X::neg(*reinterpret_cast<const uint2*>(as + a_off + mi * 16 * LROW + s * 32));
-#pragma unroll
-            for (int ni = 0; ni < W; ++ni)
-                b[ni] = *reinterpret_cast<const uint2*>(bs + b_off + ni * 16 * LROW + s * 32);
-#pragma unroll
-            for (int mi = 0; mi < W; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < W; ++ni) acc[mi][ni] = X::mma(a[mi], b[ni], acc[mi][ni]);
-        }
-        if (more) CIMRGP_SWRITE((kt + 1) & 1, kt + 1);
-        __syncthreads();
-    }
-#undef CIMRGP_GLOAD
-#undef CIMRGP_SWRITE
-
-    STAMP(18);
-    int Mv = M, Nv = N;
-    asm volatile("" : "+s"(Mv), "+s"(Nv));      // recompute the store predicates here (not hoisted over the loop)
-    // epilogue: store the tile (f64 map: 16 lanes x 8 B = one 128-byte line per row)
-#pragma unroll
-    for (int mi = 0; mi < W; ++mi) {
-#pragma unroll
-        for (int ni = 0; ni < W; ++ni) {
-            const int gc = col0 + wc * 16 * W + ni * 16 + (lane & 15);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gr = row0 + wr * 16 * W + mi * 16 + X::crow(lane, r);
-                if ((!EDGE || (gr < Mv && gc < Nv)) && (!diag_tile || gc <= gr)) C[(int64_t)gr * ldc + gc] = acc[mi][ni][r];
-            }
-        }
-    }
-    STAMP(19);
-}
 
 // One workgroup = one tile.  Whether the tile needs bounds handling is decided per workgroup,
 // so a ragged matrix (e.g. 2050 carried rows) pays for it only in its last row/column of tiles.
@@ -241,18 +73,56 @@ void k_gemm_nt_sub(T* __restrict__ C, int64_t ldc,
 // workgroup per unit) and leaves the others to whatever else is running -- the factorisation's
 // latency-bound panel chain: a spatial split of the machine without CU masks.
 // ---------------------------------------------------------------------------
-template <typename T, bool LOWER>
-static __device__ __forceinline__ void pers_tile_of(int id, int tiles_n, int& ti, int& tj)
+// Tile order of the persistent kernel.  Tiles are numbered strip by strip (a strip = PERS_STRIP rows of
+// tiles), column by column inside a strip, so that a run of ~32 consecutive numbers is a patch of
+// PERS_STRIP rows x ~8 columns of tiles: 4 row blocks of A and ~8 of B serve 32 tiles.  Workgroup w
+// belongs (for speed only: observed placement, never correctness) to XCD w % 8 and is its workgroup
+// number w / 8; in round r the workgroups of XCD x take the run of numbers (8 r + x) * per_xcd ...,
+// so the tiles that share operand blocks are multiplied at the same time on compute units that share
+// an L2.  (With tiles dealt out in plain row-major order every B block was used by one tile per XCD and
+// round: TCC hit rate 45 %, 500 MB of the 1 GB of operand reads per launch at M = 7936 came from beyond L2.)
+constexpr int PERS_STRIP = 4;
+
+template <bool LOWER>
+static __device__ __forceinline__ void pers_tile_decode(int q, int tiles_m, int tiles_n, int& ti, int& tj)
 {
     if (LOWER) {
-        ti = (int)((sqrtf(8.0f * (float)id + 1.0f) - 1.0f) * 0.5f);
-        while (ti * (ti + 1) / 2 > id) --ti;
-        while ((ti + 1) * (ti + 2) / 2 <= id) ++ti;
-        tj = id - ti * (ti + 1) / 2;
+        // strip s holds rows [S s, min(S s + S, tiles_m)); column c of a strip holds its rows >= c
+        int s = 0, base = 0;
+        for (;; ++s) {
+            const int r0 = PERS_STRIP * s;
+            const int h = min(PERS_STRIP, tiles_m - r0);
+            const int cnt = h * r0 + h * (h + 1) / 2;
+            if (q < base + cnt) {
+                const int off = q - base;
+                if (off < h * r0) { tj = off / h; ti = r0 + off - tj * h; return; }
+                int o2 = off - h * r0;              // inside the h x h triangle on the diagonal, column by column
+                int c = 0;
+                while (o2 >= h - c) { o2 -= h - c; ++c; }
+                tj = r0 + c;
+                ti = r0 + c + o2;
+                return;
+            }
+            base += cnt;
+        }
     } else {
-        ti = id / tiles_n;
-        tj = id - ti * tiles_n;
+        const int per_strip = PERS_STRIP * tiles_n;
+        const int s = q / per_strip;
+        const int r0 = PERS_STRIP * s;
+        const int h = min(PERS_STRIP, tiles_m - r0);
+        const int off = q - s * per_strip;
+        tj = off / h;
+        ti = r0 + off - tj * h;
     }
+}
+
+// the i-th tile (i = 0, 1, ...) of workgroup w of `grid`: -1 when there is none
+static __device__ __forceinline__ int pers_tile_number(int w, int i, int grid, int ntiles)
+{
+    const int per_xcd = grid >> 3;               // grid is a multiple of 8 (launcher)
+    const int x = w & 7, j = w >> 3;
+    const int q = (i * 8 + x) * per_xcd + j;
+    return q < ntiles ? q : -1;
 }
 
 // The C stream of the persistent kernel is cut into 16 "events" per tile and wave, one per K stage
@@ -272,7 +142,7 @@ constexpr int PERS_STAGES = 16;
 template <typename T, bool LOWER>
 __global__ __launch_bounds__(PERS_THREADS)
 void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int64_t lda,
-                    const T* __restrict__ B, int64_t ldb, int tiles_n, int ntiles)
+                    const T* __restrict__ B, int64_t ldb, int tiles_m, int tiles_n, int ntiles)
 {
     using X = Mx<T>;
     using acc_t = typename X::acc_t;
@@ -287,7 +157,7 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;                 // 2 x 4 waves: 64 rows x 32 columns each
     const int sc = tid & 7, sr = tid >> 3;                   // staging: 8 threads per 128-byte row segment, 64 rows per pass
-    const int stride = (int)gridDim.x;
+    const int grid = (int)gridDim.x, wg = (int)blockIdx.x;
 
     int a_off_e[2], b_off_e[2];
 #pragma unroll
@@ -302,10 +172,11 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
     const int lrow0 = wr * 64 + X::crow(lane, 0), lcol0 = wc * 32 + (lane & 15);
     const int coff = lrow0 * (int)ldc + lcol0;
 
-    int t = (int)blockIdx.x;
-    if (t >= ntiles) return;
+    int it = 0;                                   // this workgroup's tile counter
+    int t = pers_tile_number(wg, it, grid, ntiles);
+    if (t < 0) return;
     int ti, tj;
-    pers_tile_of<T, LOWER>(t, tiles_n, ti, tj);
+    pers_tile_decode<LOWER>(t, tiles_m, tiles_n, ti, tj);
     T* c_cur = C + (int64_t)ti * GT * ldc + (int64_t)tj * GT;
     const T* a_cur = A + (int64_t)ti * GT * lda;
     const T* b_cur = B + (int64_t)tj * GT * ldb;
@@ -333,7 +204,7 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
             *reinterpret_cast<v4u*>(bs_ + (sr + 64 * p) * LROW + sc * 16) = rb[p]; \
         }                                                                          \
     }
-#define PERS_FRAGS(set_, buf_, s_)                                                 \
+#define PERS_FRAGS_NF(set_, buf_, s_)                                              \
     {                                                                              \
         const unsigned char* as_ = smem + (buf_) * 2 * OP_BYTES;                   \
         const unsigned char* bs_ = as_ + OP_BYTES;                                 \
@@ -341,14 +212,26 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
             fa[set_][mi] = *reinterpret_cast<const uint2*>(as_ + a_frag + mi * 16 * LROW + (s_) * 32); \
         _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                           \
             fb[set_][ni] = *reinterpret_cast<const uint2*>(bs_ + b_frag + ni * 16 * LROW + (s_) * 32); \
-        __builtin_amdgcn_sched_barrier(0);      /* the reads stay AHEAD of the multiplies that follow */ \
     }
-#define PERS_MMA(cur_, set_)                                                       \
+#define PERS_FRAGS(set_, buf_, s_)  { PERS_FRAGS_NF(set_, buf_, s_) __builtin_amdgcn_sched_barrier(0); }   /* the reads stay AHEAD of the multiplies that follow */
+#define PERS_MMA_NF(cur_, set_)                                                    \
     {                                                                              \
         _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                         \
             const uint2 an_ = X::neg(fa[set_][mi]);                                \
             _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                       \
                 cur_[mi][ni] = X::mma(an_, fb[set_][ni], cur_[mi][ni]);            \
+        }                                                                          \
+    }
+#define PERS_MMA(cur_, set_)  { PERS_MMA_NF(cur_, set_) __builtin_amdgcn_sched_barrier(0); }
+    // one multiply, then up to six of everything else (LDS, global memory, vector and scalar ALU), eight times:
+    // the stage's bookkeeping -- LDS write of the next stage, operand and C requests, address arithmetic --
+    // is issued in the shadow of the first k-step's multiplies instead of ahead of them (both waves of a SIMD
+    // do this part at the same time: issued up front it left the matrix pipe idle for ~10 % of a stage)
+#define PERS_INTERLEAVE()                                                          \
+    {                                                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                         \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     \
+            __builtin_amdgcn_sched_group_barrier(0x096, 6, 0);                     \
         }                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                         \
     }
@@ -379,10 +262,10 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
     // of a stage is its number's parity (16 stages per tile).
 #define PERS_PASS(cur_, oth_)                                                                                   \
     {                                                                                                           \
-        const int tn_ = t + stride;                                                                             \
-        const bool has_next = tn_ < ntiles;                                                                     \
+        const int tn_ = pers_tile_number(wg, it + 1, grid, ntiles);                                             \
+        const bool has_next = tn_ >= 0;                                                                         \
         int ni_ = ti, nj_ = tj;                                                                                 \
-        if (has_next) pers_tile_of<T, LOWER>(tn_, tiles_n, ni_, nj_);                                           \
+        if (has_next) pers_tile_decode<LOWER>(tn_, tiles_m, tiles_n, ni_, nj_);                                 \
         const T* c_nxt = C + (int64_t)ni_ * GT * ldc + (int64_t)nj_ * GT;      /* no next tile: this one */     \
         const T* a_nxt = A + (int64_t)ni_ * GT * lda;                                                           \
         const T* b_nxt = B + (int64_t)nj_ * GT * ldb;                                                           \
@@ -407,8 +290,9 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
             }                                                                                                   \
             /* k-step s+1's fragments are requested before k-step s is multiplied (the scheduler is fenced */  \
             /* so that it cannot fold the pairs back into read -> wait -> multiply)                        */  \
-            PERS_FRAGS(1, kt & 1, 1);                                                                           \
-            PERS_MMA(cur_, 0);                                                                                  \
+            PERS_FRAGS_NF(1, kt & 1, 1);                                                                        \
+            PERS_MMA_NF(cur_, 0);                                                                               \
+            PERS_INTERLEAVE();                                                                                  \
             PERS_FRAGS(0, kt & 1, 2);                                                                           \
             PERS_MMA(cur_, 1);                                                                                  \
             PERS_FRAGS(1, kt & 1, 3);                                                                           \
@@ -430,7 +314,7 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
                         (c_cur + ((int64_t)(mi * 16 + RS * r) * ldc + ni * 16))[coff] = cur_[mi][ni][r];        \
             return;                                                                                             \
         }                                                                                                       \
-        t = tn_; ti = ni_; tj = nj_;                                                                            \
+        t = tn_; ti = ni_; tj = nj_; ++it;                                                                      \
         c_cur = const_cast<T*>(c_nxt); a_cur = a_nxt; b_cur = b_nxt;                                            \
     }
 
@@ -439,7 +323,10 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
         PERS_PASS(acc1, acc0)
     }
 #undef PERS_PASS
+#undef PERS_INTERLEAVE
 #undef PERS_MMA
+#undef PERS_MMA_NF
+#undef PERS_FRAGS_NF
 #undef PERS_FRAGS
 #undef PERS_SWRITE
 #undef PERS_GLOAD
@@ -498,15 +385,18 @@ int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t 
         constexpr int bke = KT_BYTES / (int)sizeof(T);
         const int want = (bt.pers >= 0) ? bt.pers : knobs().gemm_pers;
         const int nkt = (k % bke) ? 0 : k / bke;
-        if (want > 0 && nkt == PERS_STAGES && bt.count == 1 && !bt.skip_first && m % 128 == 0 && n % 128 == 0 &&
+        if (want >= 8 && nkt == PERS_STAGES && bt.count == 1 && !bt.skip_first && m % 128 == 0 && n % 128 == 0 &&
             ldc < (1ll << 23) && lda < (1ll << 23) && ldb < (1ll << 23) && t128 >= knobs().pers_min_tiles) {
             const int64_t tm = m / 128, tn = n / 128;
             const int64_t tiles = lower ? tm * (tm + 1) / 2 : tm * tn;
-            const int cus = want < 256 ? want : 256;            // one workgroup per compute unit (gfx950: 256)
+            const int cus = (want < 256 ? want : 256) & ~7;     // one workgroup per compute unit (gfx950: 256), 8 XCDs
             const int64_t rounds = (tiles + cus - 1) / cus;
-            const dim3 grid((unsigned)((tiles + rounds - 1) / rounds));          // every workgroup busy in every round
+            int64_t g8 = (tiles + rounds - 1) / rounds;         // every workgroup busy in (nearly) every round ...
+            g8 = (g8 + 7) / 8 * 8;                              // ... and the same number of them on every XCD
+            if (g8 > cus) g8 = cus;
+            const dim3 grid((unsigned)g8);
 #define CIMRGP_PERS_LAUNCH(LOW_) \
-            hipLaunchKernelGGL((k_gemm_nt_pers<T, LOW_>), grid, dim3(PERS_THREADS), 0, st, c, ldc, a, lda, b, ldb, (int)tn, (int)tiles)
+            hipLaunchKernelGGL((k_gemm_nt_pers<T, LOW_>), grid, dim3(PERS_THREADS), 0, st, c, ldc, a, lda, b, ldb, (int)tm, (int)tn, (int)tiles)
             if (lower) CIMRGP_PERS_LAUNCH(true); else CIMRGP_PERS_LAUNCH(false);
 #undef CIMRGP_PERS_LAUNCH
             CIMRGP_LAUNCH_CHECK(fn);

@@ -11,6 +11,7 @@
 // The inverted 64x64 diagonal blocks stay in the workspace (slab c0/64) and
 // are what cimrgp_potrs / cimrgp_trsm_rows use afterwards.
 #include "common.hpp"
+#include "gemm_tile.hpp"
 #include <cstdlib>
 #include <mutex>
 
@@ -247,6 +248,76 @@ template <> __device__ __forceinline__ float rsqrt_refined<float>(float d)
 }
 
 // ---------------------------------------------------------------------------
+// Riders (round 3).  The launches of a panel's chain are latency-bound: one workgroup factors a 64 x 64
+// block for 17-31 us while the 30-250 panel-solve workgroups beside it are gone after ~10 us and most
+// compute units idle.  In the one-queue sweeps (small matrices, batches, the tail of a large
+// factorisation) the trailing updates therefore no longer get launches of their own: they are cut into
+// 64 x 64 tiles (gemm_tile, W = 2) that ride as extra workgroups of the chain's launches -- the update by
+// the PREVIOUS panel in the launches of this panel's chain, and the update of the next panel's columns by
+// this panel sub-block by sub-block (K = 64) as soon as a sub-block is final, so that the next chain
+// never waits for a "head" update either (fused_sweep has the schedule).  One queue, no inter-queue
+// signal, and the chain's workgroup 0 is dispatched first in its launch.
+// ---------------------------------------------------------------------------
+template <typename T> struct RiderJob {
+    T* c; const T* a; const T* b;      // C[m x n] -= A[m x k] B[n x k]^T
+    int64_t ldc, lda, ldb;
+    int m, n, k;
+    int lower;                          // 1: lower-triangular grid of tiles (square C), 0: rectangular
+    int tiles_n;                        // tiles per row of the rectangular grid
+    int first, count;                   // this launch runs tiles [first, first + count) of the job
+    int skip00;                         // tile (0, 0) is left alone: the chain's workgroup 0 owns it
+    int rows_job;                       // 1: c and a are carried rows (batch stride sb), 0: the matrix (stride sk)
+};
+constexpr int MAX_RIDER_JOBS = 4;
+template <typename T> struct Riders {
+    RiderJob<T> job[MAX_RIDER_JOBS];
+    int njobs;
+    int total;                          // sum of the jobs' counts = extra workgroups of the launch
+};
+template <typename T> static Riders<T> no_riders() { Riders<T> r; r.njobs = 0; r.total = 0; return r; }
+
+constexpr int RIDER_LDS = 4 * 64 * (128 + 16);      // gemm_tile<.., W = 2>: 2 stages x 2 operands x 64 rows x 144 bytes
+// LDS of a chain kernel that also hosts riders: the larger of the panel solve's area and a rider's (f32: the rider's)
+template <typename T> struct ChainLds {
+    static constexpr int TRSM = (2 * 32 + 64) * (64 * (int)sizeof(T) + 16);          // = TrsmLds<T>::BYTES
+    static constexpr int BYTES = TRSM > RIDER_LDS ? TRSM : RIDER_LDS;
+};
+
+// Workgroup number r (0 <= r < rd.total) of a launch's riders; the first 256 threads of the workgroup.
+template <typename T>
+static __device__ __forceinline__ void run_rider(unsigned char* smem, const Riders<T>& rd, int r, int64_t sk, int64_t sb)
+{
+    int j = 0;
+    while (j + 1 < rd.njobs && r >= rd.job[j].count) { r -= rd.job[j].count; ++j; }       // uniform
+    const RiderJob<T>& jb = rd.job[j];
+    const int id = jb.first + r;
+    int ti, tj;
+    if (jb.lower) {
+        ti = (int)((sqrtf(8.0f * (float)id + 1.0f) - 1.0f) * 0.5f);
+        while (ti * (ti + 1) / 2 > id) --ti;
+        while ((ti + 1) * (ti + 2) / 2 <= id) ++ti;
+        tj = id - ti * (ti + 1) / 2;
+    } else {
+        ti = id / jb.tiles_n;
+        tj = id - ti * jb.tiles_n;
+    }
+    if (jb.skip00 && ti == 0 && tj == 0) return;
+    const int64_t off_ca = (int64_t)blockIdx.y * (jb.rows_job ? sb : sk);
+    T* c = jb.c + off_ca;
+    const T* a = jb.a + off_ca;
+    const T* b = jb.b + (int64_t)blockIdx.y * sk;
+    constexpr int BKE = 128 / (int)sizeof(T);
+    const bool interior = (ti + 1) * 64 <= jb.m && (tj + 1) * 64 <= jb.n && (jb.k % BKE) == 0;
+    if (jb.lower) {
+        if (interior) gemm_tile<T, true, false, 2>(smem, c, jb.ldc, a, jb.lda, b, jb.ldb, jb.m, jb.n, jb.k, ti, tj);
+        else          gemm_tile<T, true, true, 2>(smem, c, jb.ldc, a, jb.lda, b, jb.ldb, jb.m, jb.n, jb.k, ti, tj);
+    } else {
+        if (interior) gemm_tile<T, false, false, 2>(smem, c, jb.ldc, a, jb.lda, b, jb.ldb, jb.m, jb.n, jb.k, ti, tj);
+        else          gemm_tile<T, false, true, 2>(smem, c, jb.ldc, a, jb.lda, b, jb.ldb, jb.m, jb.n, jb.k, ti, tj);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Diagonal 64x64 sub-block of a panel (left-looking inside the panel):
 //   S = A_ss - Lrow Lrow^T        Lrow = the kprev panel columns left of the
 //                                 block, already final (MFMA, K = kprev <= 192)
@@ -479,8 +550,15 @@ template <typename T> struct DiagLds {
 template <typename T>
 __global__ __launch_bounds__(DG_NT)
 void k_diag64(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow, int kprev,
-              T* __restrict__ inv, int32_t* info, int col_base, int64_t sk = 0, int64_t sws = 0)
+              T* __restrict__ inv, int32_t* info, int col_base, int64_t sk, int64_t sws, int64_t sb, Riders<T> rd)
 {
+    static_assert(Tile64<T>::BYTES <= RIDER_LDS, "the prologue chunk and a rider's tiles share one LDS area");
+    __shared__ __attribute__((aligned(16))) unsigned char chunk[RIDER_LDS];           // Lrow chunk of the prologue / a rider's tiles
+    if (blockIdx.x != 0) {                           // riders: update tiles in the shadow of the pivot loop
+        if (threadIdx.x >= 256) return;
+        run_rider<T>(chunk, rd, (int)blockIdx.x - 1, sk, sb);
+        return;
+    }
     // batch of independent factorisations (blocks of one layer): blockIdx.y selects the matrix
     D += (int64_t)blockIdx.y * sk;
     Lrow += (int64_t)blockIdx.y * sk;
@@ -491,7 +569,6 @@ void k_diag64(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow, 
     using acc_t = typename X::acc_t;
     constexpr int TT = 64 * DG_TW;                                            // threads of the tile waves
     static_assert(DG_TW == 8 && DG_NW == 9, "tile ownership below assumes 8 tile waves + 1 pivot wave");
-    __shared__ __attribute__((aligned(16))) unsigned char chunk[TL::BYTES];   // Lrow chunk of the prologue
     __shared__ __attribute__((aligned(16))) unsigned char pcol_[DiagLds<T>::PCOL];   // gathered pivot columns, double buffered
     __shared__ __attribute__((aligned(16))) unsigned char hs_[DiagLds<T>::PCOL];     // left operand (per row), double buffered
     __shared__ __attribute__((aligned(16))) unsigned char cs_[DiagLds<T>::CS];       // right operand = pivot-time columns, kept
@@ -671,8 +748,13 @@ __global__ __launch_bounds__(256)
 void k_trsm64(T* __restrict__ P1, int64_t ld1, int M1, int nb1,
               T* __restrict__ P2, int64_t ld2, int M2,
               int kw, int kprev, const T* __restrict__ Lrow, int64_t ldl, const T* __restrict__ invL,
-              int64_t sk = 0, int64_t sws = 0, int64_t sb = 0)
+              int64_t sk, int64_t sws, int64_t sb, int nchain, Riders<T> rd)
 {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[ChainLds<T>::BYTES];
+    if ((int)blockIdx.x >= nchain) {                 // riders
+        run_rider<T>(smem, rd, (int)blockIdx.x - nchain, sk, sb);
+        return;
+    }
     P1 += (int64_t)blockIdx.y * sk;                  // batch: see k_diag64
     if (P2) P2 += (int64_t)blockIdx.y * sb;
     Lrow += (int64_t)blockIdx.y * sk;
@@ -682,7 +764,6 @@ void k_trsm64(T* __restrict__ P1, int64_t ld1, int M1, int nb1,
     const int64_t ldp = second ? ld2 : ld1;
     const int M = second ? M2 : M1;
     const int row0 = (second ? (int)blockIdx.x - nb1 : (int)blockIdx.x) * TR;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[TrsmLds<T>::BYTES];
     trsm64_body<T>(smem, P + (int64_t)row0 * ldp, ldp, min(TR, M - row0), kw, kprev, Lrow, ldl, invL);
 }
 
@@ -704,8 +785,14 @@ template <typename T>
 __global__ __launch_bounds__(DG_NT)
 void k_link(T* __restrict__ A, int64_t ld, int n, int c0, int k0, int wn,
             T* __restrict__ P2, int64_t ld2, int M2, T* __restrict__ ws, int32_t* info,
-            int64_t sk = 0, int64_t sws = 0, int64_t sb = 0)
+            int64_t sk, int64_t sws, int64_t sb, int nchain, Riders<T> rd)
 {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[ChainLds<T>::BYTES];
+    if ((int)blockIdx.x >= nchain) {                 // riders
+        if (threadIdx.x >= 256) return;
+        run_rider<T>(smem, rd, (int)blockIdx.x - nchain, sk, sb);
+        return;
+    }
     A += (int64_t)blockIdx.y * sk;                   // batch: see k_diag64
     ws += (int64_t)blockIdx.y * sws;
     if (P2) P2 += (int64_t)blockIdx.y * sb;
@@ -713,7 +800,6 @@ void k_link(T* __restrict__ A, int64_t ld, int n, int c0, int k0, int wn,
     using X = Mx<T>;
     using TL = Tile64<T>;
     using acc_t = typename X::acc_t;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[TrsmLds<T>::BYTES];
     const int kprev = c0 - k0;
     const T* invL = ws + (int64_t)(c0 / SB) * (SB * SB);
     const T* Lrow = A + (int64_t)c0 * ld + k0;       // rows of the factored diagonal block, earlier panel columns
@@ -998,8 +1084,13 @@ static __device__ __forceinline__ void schur_to_lds(T* __restrict__ cs, const T 
 template <typename T>
 __global__ __launch_bounds__(Q_NT, 2)
 void k_diag64q(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow, int kprev,
-               T* __restrict__ inv, int32_t* info, int col_base, int64_t sk = 0, int64_t sws = 0)
+               T* __restrict__ inv, int32_t* info, int col_base, int64_t sk, int64_t sws, int64_t sb, Riders<T> rd)
 {
+    __shared__ __attribute__((aligned(16))) unsigned char chunk[RIDER_LDS];           // Lrow chunk / a rider's tiles
+    if (blockIdx.x != 0) {                           // riders
+        run_rider<T>(chunk, rd, (int)blockIdx.x - 1, sk, sb);
+        return;
+    }
     D += (int64_t)blockIdx.y * sk;
     Lrow += (int64_t)blockIdx.y * sk;
     inv += (int64_t)blockIdx.y * sws;
@@ -1007,7 +1098,6 @@ void k_diag64q(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow,
     using X = Mx<T>;
     using TL = Tile64<T>;
     using acc_t = typename X::acc_t;
-    __shared__ __attribute__((aligned(16))) unsigned char chunk[TL::BYTES];
     __shared__ __attribute__((aligned(16))) unsigned char pcol_[DiagLds<T>::PCOL];
     __shared__ __attribute__((aligned(16))) unsigned char hs_[DiagLds<T>::PCOL];
     __shared__ __attribute__((aligned(16))) unsigned char cs_[DiagLds<T>::CS];
@@ -1068,8 +1158,13 @@ template <typename T>
 __global__ __launch_bounds__(Q_NT, 2)
 void k_linkq(T* __restrict__ A, int64_t ld, int n, int c0, int k0, int wn,
              T* __restrict__ P2, int64_t ld2, int M2, T* __restrict__ ws, int32_t* info,
-             int64_t sk = 0, int64_t sws = 0, int64_t sb = 0)
+             int64_t sk, int64_t sws, int64_t sb, int nchain, Riders<T> rd)
 {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[ChainLds<T>::BYTES];
+    if ((int)blockIdx.x >= nchain) {                 // riders
+        run_rider<T>(smem, rd, (int)blockIdx.x - nchain, sk, sb);
+        return;
+    }
     A += (int64_t)blockIdx.y * sk;
     ws += (int64_t)blockIdx.y * sws;
     if (P2) P2 += (int64_t)blockIdx.y * sb;
@@ -1077,7 +1172,6 @@ void k_linkq(T* __restrict__ A, int64_t ld, int n, int c0, int k0, int wn,
     using X = Mx<T>;
     using TL = Tile64<T>;
     using acc_t = typename X::acc_t;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[TrsmLds<T>::BYTES];
     const int kprev = c0 - k0;
     const T* invL = ws + (int64_t)(c0 / SB) * (SB * SB);
     const T* Lrow = A + (int64_t)c0 * ld + k0;
@@ -1315,10 +1409,14 @@ struct PanelGroup {
 // gets, by queue priority, the first slot that falls free: there the four-wave forms run
 // (N = 8192: period of the update-bound panels 437 / 391 / 371 -> 405 / 363 / 355 us).
 // (CIMRGP_CHAIN overrides the choice for measurements: see Tuning.)
+// `riders`: nullptr, or the update tiles riding in the chain's launches -- riders[0] in the first diagonal
+// block's launch, riders[1..3] in the links, riders[4] in the last sub-block's panel solve (fused_sweep).
+// `left64`: the first diagonal block takes, as its left-looking prologue, the 64 columns just left of the
+// panel (the previous panel's last sub-block, whose contribution the riders could not apply before it was final).
 template <typename T>
 static int panel_chain(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, int64_t k0, int64_t w,
                        T* b, int64_t m, int64_t ldb, PotrfBatch bt, hipStream_t st, const char* fn, bool alone,
-                       bool first_done = false)
+                       bool first_done = false, const Riders<T>* riders = nullptr, bool left64 = false)
 {
     const int chain_mode = knobs().chain_mode;
     const bool split_links = (chain_mode == 1);
@@ -1329,6 +1427,8 @@ static int panel_chain(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, int
     const unsigned nbatch = (unsigned)bt.count;
     const int64_t k1 = k0 + w;
     const int nb2 = rows ? (int)((m + TR - 1) / TR) : 0;
+    const Riders<T> none = no_riders<T>();
+    int launch = 0;                                   // 0: first diagonal block, 1..3: links, 4: last panel solve
     for (int64_t c0 = k0; c0 < k1; c0 += SB) {
         const int sw = (int)((k1 - c0 < SB) ? (k1 - c0) : SB);
         const int kprev = (int)(c0 - k0);
@@ -1336,36 +1436,44 @@ static int panel_chain(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, int
         T* inv = ws + (c0 / SB) * (SB * SB);
         const T* lrow = kmat + c0 * ld + k0;   // rows of the diagonal block, earlier panel columns
         if ((split_links || c0 == k0) && !(first_done && c0 == k0)) {
+            const Riders<T>& rd = (riders && c0 == k0) ? riders[0] : none;
+            const bool l64 = left64 && c0 == k0;
+            const T* lr = l64 ? lrow - SB : lrow;
+            const int kp = l64 ? SB : kprev;
             if (waves4)
-                hipLaunchKernelGGL((k_diag64q<T>), dim3(1, nbatch), dim3(Q_NT), 0, st,
-                                   kmat + c0 * ld + c0, ld, sw, lrow, kprev, inv, info, (int)c0, bt.sk, bt.sws);
+                hipLaunchKernelGGL((k_diag64q<T>), dim3((unsigned)(1 + rd.total), nbatch), dim3(Q_NT), 0, st,
+                                   kmat + c0 * ld + c0, ld, sw, lr, kp, inv, info, (int)c0, bt.sk, bt.sws, bt.sb, rd);
             else
-                hipLaunchKernelGGL((k_diag64<T>), dim3(1, nbatch), dim3(DG_NT), 0, st,
-                                   kmat + c0 * ld + c0, ld, sw, lrow, kprev, inv, info, (int)c0, bt.sk, bt.sws);
+                hipLaunchKernelGGL((k_diag64<T>), dim3((unsigned)(1 + rd.total), nbatch), dim3(DG_NT), 0, st,
+                                   kmat + c0 * ld + c0, ld, sw, lr, kp, inv, info, (int)c0, bt.sk, bt.sws, bt.sb, rd);
             CIMRGP_LAUNCH_CHECK(fn);
         }
         if (!split_links && pc < k1) {
             const int wn = (int)((k1 - pc < SB) ? (k1 - pc) : SB);         // next diagonal block of this panel
             const int64_t m1 = n - (pc + wn);
             const int nb1 = (int)((m1 + TR - 1) / TR);
+            ++launch;
+            const Riders<T>& rd = (riders && launch <= 3) ? riders[launch] : none;
+            const int nchain = 1 + nb1 + nb2;
             if (waves4)
-                hipLaunchKernelGGL((k_linkq<T>), dim3((unsigned)(1 + nb1 + nb2), nbatch), dim3(Q_NT), 0, st,
+                hipLaunchKernelGGL((k_linkq<T>), dim3((unsigned)(nchain + rd.total), nbatch), dim3(Q_NT), 0, st,
                                    kmat, ld, (int)n, (int)c0, (int)k0, wn, rows ? b + c0 : (T*)nullptr, ldb, rows ? (int)m : 0,
-                                   ws, info, bt.sk, bt.sws, bt.sb);
+                                   ws, info, bt.sk, bt.sws, bt.sb, nchain, rd);
             else
-                hipLaunchKernelGGL((k_link<T>), dim3((unsigned)(1 + nb1 + nb2), nbatch), dim3(DG_NT), 0, st,
+                hipLaunchKernelGGL((k_link<T>), dim3((unsigned)(nchain + rd.total), nbatch), dim3(DG_NT), 0, st,
                                    kmat, ld, (int)n, (int)c0, (int)k0, wn, rows ? b + c0 : (T*)nullptr, ldb, rows ? (int)m : 0,
-                                   ws, info, bt.sk, bt.sws, bt.sb);
+                                   ws, info, bt.sk, bt.sws, bt.sb, nchain, rd);
             CIMRGP_LAUNCH_CHECK(fn);
             continue;
         }
         const int64_t m1 = n - pc;
         const int nb1 = (int)((m1 + TR - 1) / TR);
-        if (nb1 + nb2 > 0) {
-            hipLaunchKernelGGL((k_trsm64<T>), dim3((unsigned)(nb1 + nb2), nbatch), dim3(256), 0, st,
+        const Riders<T>& rd = (riders && !split_links && pc == k1) ? riders[4] : none;
+        if (nb1 + nb2 + rd.total > 0) {
+            hipLaunchKernelGGL((k_trsm64<T>), dim3((unsigned)(nb1 + nb2 + rd.total), nbatch), dim3(256), 0, st,
                                kmat + pc * ld + c0, ld, (int)m1, nb1,
                                rows ? b + c0 : (T*)nullptr, ldb, rows ? (int)m : 0,
-                               sw, kprev, lrow, ld, (const T*)inv, bt.sk, bt.sws, bt.sb);
+                               sw, kprev, lrow, ld, (const T*)inv, bt.sk, bt.sws, bt.sb, nb1 + nb2, rd);
             CIMRGP_LAUNCH_CHECK(fn);
         }
     }
@@ -1441,6 +1549,119 @@ static int panel_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info,
                 if (rc) return rc;
             }
         }
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// One-queue factorisation with the updates riding in the chain's launches (round 3; "Riders" above).
+// Panel p = columns [k0, k1), next panel [k1, k2), previous panel `prev` = [q0, k0).  What the chain of
+// panel p needs is that its OWN columns hold every earlier panel's contribution; everything else may lag.
+//   launch              chain part                         riders
+//   D(p)   diag block 0 (+ K = 64 prologue: prev's last    PH3(prev): prev's last sub-block -> panel p's columns (not its
+//          sub-block, if PH3 is pending)                   tile (0,0)); ROWS(prev); NEAR(prev) 1st part; FAR(prev) share
+//   L1(p)  solve sub-block 0 | diag block 1                NEAR(prev) rest; FAR(prev) share
+//   L2(p)  solve sub-block 1 | diag block 2                PH(p, 0): sub-block 0 of p -> panel p+1's columns (K = 64); FAR(prev)
+//   L3(p)  solve sub-block 2 | diag block 3                PH(p, 1); FAR(prev) share
+//   T(p)   solve sub-block 3                               PH(p, 2); FAR(prev) rest
+// with  NEAR(prev) = panel p+1's columns (all rows from k1) -= prev's panel, K = 256
+//       FAR(prev)  = lower triangle from k2 on             -= prev's panel, K = 256
+//       ROWS(prev) = carried rows, columns from k0 on      -= their own prev columns x prev's panel.
+// Who writes what when: panel p's columns -- PH3(prev) in D(p) only, beside workgroup 0 on a different tile;
+// panel p+1's columns -- NEAR(prev) in D, L1, then PH(p, s) from L2 on; beyond -- FAR(prev) only; launches of
+// one queue follow one another, so each of these sets is complete before its first reader starts.
+// `prev_w` > 0: the sweep starts behind a final panel [k_begin - prev_w, k_begin) whose contribution has been
+// applied to panel k_begin's columns ONLY (the tail of a look-ahead factorisation, after its last head update).
+// ---------------------------------------------------------------------------
+template <typename T>
+static int fused_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m, int64_t ldb,
+                       PotrfBatch bt, hipStream_t st, int64_t k_begin = 0, int64_t prev_w = 0)
+{
+    const char* fn = "cimrgp_potrf";
+    const bool rows = (b != nullptr && m > 0);
+    // share of FAR(prev) (+ NEAR) given to each of the five launches: their chain parts last about
+    // 17 / 22 / 27 / 31 / 12 us alone
+    static const double share[5] = {0.16, 0.20, 0.25, 0.28, 0.11};
+    int64_t q0 = (prev_w > 0) ? k_begin - prev_w : -1;      // previous panel (-1: none)
+    int64_t qw = prev_w;
+    bool ph3_pending = false;                                // prev's last sub-block still owed to this panel's columns
+    bool rows_pending = false;                               // ROWS(prev) owed (the tail entry never has carried rows)
+    auto tiles64 = [](int64_t v) { return (v + 63) / 64; };
+    for (int64_t k0 = k_begin; k0 < n; k0 += CIMRGP_NB) {
+        const int64_t w = (n - k0 < CIMRGP_NB) ? (n - k0) : CIMRGP_NB;
+        const int64_t k1 = k0 + w;
+        const int64_t wn = (k1 < n) ? ((n - k1 < CIMRGP_NB) ? (n - k1) : CIMRGP_NB) : 0;
+        const int64_t k2 = k1 + wn;
+        Riders<T> rd[5];
+        for (int i = 0; i < 5; ++i) rd[i] = no_riders<T>();
+        auto add = [&](int launch, const RiderJob<T>& jb) {
+            if (jb.count <= 0) return;
+            Riders<T>& r = rd[launch];
+            r.job[r.njobs++] = jb;
+            r.total += jb.count;
+        };
+        auto rect_job = [&](T* c, int64_t ldc, const T* a, int64_t lda, const T* bb, int64_t ldbb, int64_t mm, int64_t nn, int64_t kk) {
+            RiderJob<T> jb;
+            jb.c = c; jb.a = a; jb.b = bb; jb.ldc = ldc; jb.lda = lda; jb.ldb = ldbb;
+            jb.m = (int)mm; jb.n = (int)nn; jb.k = (int)kk; jb.lower = 0; jb.tiles_n = (int)tiles64(nn);
+            jb.first = 0; jb.count = (int)(tiles64(mm) * tiles64(nn)); jb.skip00 = 0; jb.rows_job = 0;
+            return jb;
+        };
+        if (q0 >= 0) {
+            const T* pa = kmat + q0;                          // prev's panel columns, row r at pa + r * ld
+            if (ph3_pending) {
+                // prev's last 64 columns -> this panel's columns, every row from k0 (tile (0,0) is workgroup 0's)
+                RiderJob<T> jb = rect_job(kmat + k0 * ld + k0, ld, kmat + k0 * ld + (k0 - SB), ld, kmat + k0 * ld + (k0 - SB), ld,
+                                          n - k0, w, SB);
+                jb.skip00 = 1;
+                add(0, jb);
+            }
+            if (rows_pending) {
+                RiderJob<T> jb = rect_job(b + k0, ldb, b + q0, ldb, pa + k0 * ld, ld, m, n - k0, qw);
+                jb.rows_job = 1;
+                add(0, jb);
+            }
+            if (wn > 0) {
+                const int64_t near_tiles = tiles64(n - k1) * tiles64(wn);
+                const int64_t tf = (n > k2) ? tiles64(n - k2) : 0;
+                const int64_t far_tiles = tf * (tf + 1) / 2;
+                const double unit = (double)(near_tiles + far_tiles);
+                // NEAR(prev): launches 0 and 1 only (from launch 2 on this panel's sub-blocks update the same columns)
+                RiderJob<T> nr = rect_job(kmat + k1 * ld + k1, ld, pa + k1 * ld, ld, pa + k1 * ld, ld, n - k1, wn, qw);
+                int64_t near0 = (int64_t)(share[0] * unit);
+                if (near0 > near_tiles) near0 = near_tiles;
+                RiderJob<T> n0 = nr; n0.first = 0; n0.count = (int)near0; add(0, n0);
+                RiderJob<T> n1 = nr; n1.first = (int)near0; n1.count = (int)(near_tiles - near0); add(1, n1);
+                if (far_tiles > 0) {
+                    RiderJob<T> fr;
+                    fr.c = kmat + k2 * ld + k2; fr.a = pa + k2 * ld; fr.b = pa + k2 * ld; fr.ldc = fr.lda = fr.ldb = ld;
+                    fr.m = fr.n = (int)(n - k2); fr.k = (int)qw; fr.lower = 1; fr.tiles_n = (int)tf; fr.skip00 = 0; fr.rows_job = 0;
+                    int64_t done = 0;
+                    for (int i = 0; i < 5; ++i) {
+                        int64_t want = (int64_t)(share[i] * unit) - (i == 0 ? near0 : i == 1 ? (near_tiles - near0) : 0);
+                        if (want < 0) want = 0;
+                        if (i == 4 || want > far_tiles - done) want = far_tiles - done;
+                        RiderJob<T> part = fr; part.first = (int)done; part.count = (int)want;
+                        add(i, part);
+                        done += want;
+                    }
+                }
+            }
+        }
+        if (wn > 0 && w == CIMRGP_NB) {
+            // this panel's sub-blocks 0, 1, 2 -> the next panel's columns, each as soon as it is final
+            for (int sblk = 0; sblk < 3; ++sblk) {
+                const int64_t cs = k0 + SB * sblk;
+                add(2 + sblk, rect_job(kmat + k1 * ld + k1, ld, kmat + k1 * ld + cs, ld, kmat + k1 * ld + cs, ld, n - k1, wn, SB));
+            }
+        }
+        int rc = panel_chain<T>(kmat, n, ld, ws, info, k0, w, b, m, ldb, bt, st, fn, true, false, rd, ph3_pending);
+        if (rc) return rc;
+        q0 = k0;
+        qw = w;
+        ph3_pending = (wn > 0 && w == CIMRGP_NB);
+        rows_pending = rows && k1 < n;
+        // a ragged panel that still has columns to its right cannot happen (only the last panel is ragged)
     }
     return 0;
 }
@@ -1607,7 +1828,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     // their callers' streams, which fills the machine better than look-ahead inside each of them.
     LookAhead* la = (n > SINGLE_QUEUE_MAX && npanels > 2) ? acquire_ctx(st) : nullptr;
     if (la == nullptr) {
-        int rc0 = panel_sweep<T, true>(k, n, ld, ws, info, b, m, ldb, st);
+        int rc0 = fused_sweep<T>(k, n, ld, ws, info, b, m, ldb, PotrfBatch(), st);
         return rc0 ? rc0 : build_invT<T>(k, n, ld, ws, st);
     }
 
@@ -1727,25 +1948,16 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
             // panels' updates once the bulk queue has drained.
             CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0), "hipStreamWaitEvent");
             if (sb != st && ev_bulk_last) CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_bulk_last, 0), "hipStreamWaitEvent");
-            hipEvent_t ev_fin = ev_panel;
-            for (int64_t p0 = k0; p0 < n; p0 += CIMRGP_NB) {
-                const int64_t pw = (n - p0 < CIMRGP_NB) ? (n - p0) : CIMRGP_NB;
-                const int64_t p1 = p0 + pw;
-                rc = rows_after_panel(p0, p1, ev_fin);
+            // (this branch is taken without carried rows only)  Round 3: the tail is the fused one-queue sweep --
+            // the head update of panel k0 (the next panel's columns, all rows) in a launch of its own, everything
+            // after it rides in the chains' launches (fused_sweep).
+            {
+                const int64_t kn = k1 + ((n - k1 < CIMRGP_NB) ? (n - k1) : CIMRGP_NB);
+                rc = gemm_nt_sub<T>(k + k1 * ld + k1, ld, k + k1 * ld + k0, ld, k + k1 * ld + k0, ld,
+                                    n - k1, kn - k1, (int)w, false, st);
                 if (rc) return rc;
-                if (p1 >= n) break;
-                const double mm = (double)(n - p1);
-                hipEvent_t rec = rec_open(st, mm * (mm + 1.0) * (double)pw);
-                rc = gemm_nt_sub<T>(k + p1 * ld + p1, ld, k + p1 * ld + p0, ld, k + p1 * ld + p0, ld,
-                                    n - p1, n - p1, (int)pw, true, st);
-                if (rec) (void)hipEventRecord(rec, st);
+                rc = fused_sweep<T>(k, n, ld, ws, info, (T*)nullptr, 0, 0, PotrfBatch(), st, k1, w);
                 if (rc) return rc;
-                rc = factor_panel<T>(k, n, ld, ws, info, p1, (n - p1 < CIMRGP_NB) ? (n - p1) : CIMRGP_NB, st, true);
-                if (rc) return rc;
-                if (rows && la->rows) {
-                    ev_fin = la->ev[ne++];
-                    CIMRGP_HIP_TRY(hipEventRecord(ev_fin, st), "hipEventRecord");
-                }
             }
             tail_done = true;
             break;
@@ -1769,7 +1981,8 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
             if (head0) {
                 const int sw0 = (int)((wn < SB) ? wn : SB);
                 hipLaunchKernelGGL((k_diag64q<T>), dim3(1), dim3(Q_NT), 0, sp, k + k1 * ld + k1, ld, sw0,
-                                   (const T*)(k + k1 * ld + k0), (int)w, ws + (k1 / SB) * (SB * SB), info, (int)k1, (int64_t)0, (int64_t)0);
+                                   (const T*)(k + k1 * ld + k0), (int)w, ws + (k1 / SB) * (SB * SB), info, (int)k1, (int64_t)0, (int64_t)0,
+                                   (int64_t)0, no_riders<T>());
                 CIMRGP_LAUNCH_CHECK("cimrgp_potrf");
             }
             GemmBatch ghead; ghead.skip_first = head0 ? 1 : 0;
@@ -1876,7 +2089,7 @@ int potrf_batched_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, i
     if (bt.count < 1 || bt.count >= 65536) return fail("cimrgp_potrf_batched", "batch count out of range");
     hipError_t e = hipMemsetAsync(info, 0, sizeof(int32_t) * (size_t)bt.count, st);
     if (e != hipSuccess) return check_hip(e, "cimrgp_potrf_batched", "hipMemsetAsync(info)");
-    int rc = panel_sweep<T, true>(k, n, ld, ws, info, b, m, ldb, st, bt);
+    int rc = fused_sweep<T>(k, n, ld, ws, info, b, m, ldb, bt, st);
     return rc ? rc : build_invT<T>(k, n, ld, ws, st, bt);
 }
 

@@ -106,6 +106,7 @@ def test_layer_fit_reports_non_pd_block(dev):
     """A block with a duplicated point and (almost) no noise must come back with LAPACK's info, the others clean."""
     nb, n, d, q = 3, 192, 1, 2
     x, y, fbar, starts = _layer(nb, n, d, q, seed=3)
+    x = np.linspace(-1.7, 1.7, x.shape[0])[:, None]          # evenly spaced: distinct points, spacing ~0.0055
     a = int(starts[1])
     x[a + 100] = x[a + 50]                                   # singular Gram matrix in block 1
     tdt = torch.float64
@@ -119,10 +120,13 @@ def test_layer_fit_reports_non_pd_block(dev):
     noise = torch.empty(nb, dtype=tdt, device="cuda")
     z = torch.empty((nb, n, q), dtype=tdt, device="cuda")
     alpha = torch.empty((nb, n, q), dtype=tdt, device="cuda")
-    dev.layer_fit(xd, yd, fd, torch.zeros_like(yd), torch.as_tensor(starts).cuda(), n, 0.4, 1.0, 0.0, 0.01, 0.0, None, None,
+    # length-scale of about one point spacing and NO noise: distinct points give a well-conditioned matrix,
+    # the duplicated pair an exactly singular one
+    ell = 0.005
+    dev.layer_fit(xd, yd, fd, torch.zeros_like(yd), torch.as_tensor(starts).cuda(), n, ell, 1.0, 0.0, 0.01, 0.0, None, None,
                   karena, ws_arena, info, bias, noise, z, alpha)
     got = info.cpu().numpy()
     assert got[0] == 0 and got[2] == 0
-    k1 = oracle.rbf_gram(x[a:a + n], None, 0.4, 1.0, 0.0)
+    k1 = oracle.rbf_gram(x[a:a + n], None, ell, 1.0, 0.0)
     _, want = oracle.potrf_lower(k1)
     assert want > 0 and got[1] > 0 and abs(int(got[1]) - want) <= 1   # rounding may move the failing pivot by one

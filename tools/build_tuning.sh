@@ -10,7 +10,7 @@ mkdir -p tuning_obj
 pids=()
 OBJS=()
 for f in api gemm_nt potrf gram solve misc reduced layer; do
-    if [ ! -f "tuning_obj/$f.o" ] || [ "$f.hip" -nt "tuning_obj/$f.o" ] || [ common.hpp -nt "tuning_obj/$f.o" ] || [ ../../include/cimrgp.h -nt "tuning_obj/$f.o" ]; then
+    if [ ! -f "tuning_obj/$f.o" ] || [ "$f.hip" -nt "tuning_obj/$f.o" ] || [ common.hpp -nt "tuning_obj/$f.o" ] || [ gemm_tile.hpp -nt "tuning_obj/$f.o" ] || [ ../../include/cimrgp.h -nt "tuning_obj/$f.o" ]; then
         $HIPCC $FLAGS -c "$f.hip" -o "tuning_obj/$f.o" &
         pids+=($!)
     fi

@@ -14,7 +14,7 @@ for pers in 0 256; do
     d=$OUT/${TAG}_pmc_p${pers}_$i
     timeout -k 10 200 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $d -- python3 tools/gemm_bench.py --m 7936 --k 256 --reps 5 > $d.log 2>&1 || { echo "pass failed: $pass"; tail -5 $d.log; }
   done
-  python3 tools/pmc_summary.py $OUT/${TAG}_pmc_p${pers}_* > $OUT/${TAG}_pmc_pers${pers}.json 2> $OUT/${TAG}_pmc_pers${pers}.err || tail -3 $OUT/${TAG}_pmc_pers${pers}.err
+  python3 tools/pmc_summary.py $OUT/${TAG}_pmc_p${pers}_*/ > $OUT/${TAG}_pmc_pers${pers}.json 2> $OUT/${TAG}_pmc_pers${pers}.err || tail -3 $OUT/${TAG}_pmc_pers${pers}.err
   rm -rf $OUT/${TAG}_pmc_p${pers}_*/
 done
 python3 - <<PY
