@@ -138,8 +138,10 @@ int profile_collect(double* total_ms, double* total_flops, int64_t* launches);
 // skip_first: the first 64 x 64 tile of a rectangular update is left alone (the chain has already
 // replaced it by its factor; only honoured when the launch uses 64-tiles: gemm_uses_tile64)
 // pers: compute units for the persistent form of the update (-1: knobs().gemm_pers, 0: never)
-struct GemmBatch { int count = 1; int64_t sc = 0, sa = 0, sb = 0; int skip_first = 0; int pers = -1; };
+// head_first + flag: the look-ahead's combined head + bulk update as one persistent launch (gemm_nt.hip)
+struct GemmBatch { int count = 1; int64_t sc = 0, sa = 0, sb = 0; int skip_first = 0; int pers = -1; int head_first = 0; int* flag = nullptr; };
 bool gemm_uses_tile64(int64_t m, int64_t n, bool lower, int count = 1);
+int gemm_pers_head_tiles(int64_t m, int k, int elem_bytes);
 template <typename T> int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t ldb,
                                       int64_t m, int64_t n, int k, bool lower, hipStream_t st, GemmBatch bt = GemmBatch());
 

@@ -116,6 +116,22 @@ static __device__ __forceinline__ void pers_tile_decode(int q, int tiles_m, int 
     }
 }
 
+// "Head first" order of a lower-triangular update (the factorisation's look-ahead): the two leftmost tile
+// columns -- the next panel's 256 columns, which the panel chain waits for -- come first, (ti, 0) for
+// ti = 1 ..., then (ti, 1); tile (0, 0) is NOT part of the launch (the chain's first diagonal block owns its
+// top-left 64 x 64 and takes the rest of that tile along); the remaining triangle follows in strip order.
+// heads = 2 tiles_m - 2 tiles come first.
+static __device__ __forceinline__ void pers_tile_decode_head_first(int q, int tiles_m, int& ti, int& tj)
+{
+    if (q < tiles_m - 1) { ti = q + 1; tj = 0; return; }
+    q -= tiles_m - 1;
+    if (q < tiles_m - 1) { ti = q + 1; tj = 1; return; }
+    q -= tiles_m - 1;
+    pers_tile_decode<true>(q, tiles_m - 2, 0, ti, tj);
+    ti += 2;
+    tj += 2;
+}
+
 // the i-th tile (i = 0, 1, ...) of workgroup w of `grid`: -1 when there is none
 static __device__ __forceinline__ int pers_tile_number(int w, int i, int grid, int ntiles)
 {
@@ -142,7 +158,7 @@ constexpr int PERS_STAGES = 16;
 template <typename T, bool LOWER>
 __global__ __launch_bounds__(PERS_THREADS)
 void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int64_t lda,
-                    const T* __restrict__ B, int64_t ldb, int tiles_m, int tiles_n, int ntiles)
+                    const T* __restrict__ B, int64_t ldb, int tiles_m, int tiles_n, int ntiles, int heads, int* __restrict__ flag)
 {
     using X = Mx<T>;
     using acc_t = typename X::acc_t;
@@ -172,11 +188,27 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
     const int lrow0 = wr * 64 + X::crow(lane, 0), lcol0 = wc * 32 + (lane & 15);
     const int coff = lrow0 * (int)ldc + lcol0;
 
+    // heads > 0: head-first order (above); every one of the first `heads` tiles, once STORED, adds 1 to *flag
+    auto decode = [&](int q, int& i_, int& j_) {
+        if (LOWER && heads > 0) pers_tile_decode_head_first(q, tiles_m, i_, j_);
+        else pers_tile_decode<LOWER>(q, tiles_m, tiles_n, i_, j_);
+    };
+    auto signal_stored = [&]() {
+        // every wave's stores have left it, then one release for the workgroup and the count
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
     int it = 0;                                   // this workgroup's tile counter
     int t = pers_tile_number(wg, it, grid, ntiles);
     if (t < 0) return;
     int ti, tj;
-    pers_tile_decode<LOWER>(t, tiles_m, tiles_n, ti, tj);
+    decode(t, ti, tj);
+    bool prev_head = false;                       // the tile being stored during this pass is one the chain waits for
     T* c_cur = C + (int64_t)ti * GT * ldc + (int64_t)tj * GT;
     const T* a_cur = A + (int64_t)ti * GT * lda;
     const T* b_cur = B + (int64_t)tj * GT * ldb;
@@ -265,7 +297,7 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
         const int tn_ = pers_tile_number(wg, it + 1, grid, ntiles);                                             \
         const bool has_next = tn_ >= 0;                                                                         \
         int ni_ = ti, nj_ = tj;                                                                                 \
-        if (has_next) pers_tile_decode<LOWER>(tn_, tiles_m, tiles_n, ni_, nj_);                                 \
+        if (has_next) decode(tn_, ni_, nj_);                                                                    \
         const T* c_nxt = C + (int64_t)ni_ * GT * ldc + (int64_t)nj_ * GT;      /* no next tile: this one */     \
         const T* a_nxt = A + (int64_t)ni_ * GT * lda;                                                           \
         const T* b_nxt = B + (int64_t)nj_ * GT * ldb;                                                           \
@@ -305,6 +337,8 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
         /* the last two events of the pass: the next tile's C is complete in `oth` */                          \
         oth_[3][1][0] = tld[0][0]; oth_[3][1][1] = tld[0][1];                                                   \
         oth_[3][1][2] = tld[1][0]; oth_[3][1][3] = tld[1][1];                                                   \
+        if (prev_head) signal_stored();             /* the previous tile's last store went out in this pass */  \
+        prev_head = (t < heads);                                                                                \
         c_prv = c_cur;                                                                                          \
         if (!has_next) {                                                                                        \
             /* last tile of this workgroup: store it directly (the previous one went out during the pass) */   \
@@ -312,6 +346,7 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
                 _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                \
                     _Pragma("unroll") for (int r = 0; r < 4; ++r)                                               \
                         (c_cur + ((int64_t)(mi * 16 + RS * r) * ldc + ni * 16))[coff] = cur_[mi][ni][r];        \
+            if (prev_head) signal_stored();                                                                     \
             return;                                                                                             \
         }                                                                                                       \
         t = tn_; ti = ni_; tj = nj_; ++it;                                                                      \
@@ -353,6 +388,15 @@ static int gemm_launch(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, i
     return 0;
 }
 
+// Whether a lower update of this shape can run as ONE head-first persistent launch (potrf_run), and how many
+// head tiles it then signals.
+int gemm_pers_head_tiles(int64_t m, int k, int elem_bytes)
+{
+    const int bke = KT_BYTES / elem_bytes;
+    if (knobs().gemm_pers < 8 || m % 128 != 0 || m / 128 < 3 || k % bke != 0 || k / bke != PERS_STAGES) return 0;
+    return (int)(2 * (m / 128) - 2);
+}
+
 // The tile-size rule of gemm_nt_sub, for callers that rely on the 64-tile grid (skip_first).
 bool gemm_uses_tile64(int64_t m, int64_t n, bool lower, int count)
 {
@@ -386,9 +430,12 @@ int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t 
         const int want = (bt.pers >= 0) ? bt.pers : knobs().gemm_pers;
         const int nkt = (k % bke) ? 0 : k / bke;
         if (want >= 8 && nkt == PERS_STAGES && bt.count == 1 && !bt.skip_first && m % 128 == 0 && n % 128 == 0 &&
-            ldc < (1ll << 23) && lda < (1ll << 23) && ldb < (1ll << 23) && t128 >= knobs().pers_min_tiles) {
+            ldc < (1ll << 23) && lda < (1ll << 23) && ldb < (1ll << 23) && (t128 >= knobs().pers_min_tiles || bt.head_first)) {
             const int64_t tm = m / 128, tn = n / 128;
-            const int64_t tiles = lower ? tm * (tm + 1) / 2 : tm * tn;
+            // head-first launch (the look-ahead's combined head + bulk update): tile (0, 0) is left to the chain
+            const int heads = (bt.head_first && lower && tm >= 3) ? (int)(2 * tm - 2) : 0;
+            CIMRGP_REQUIRE(!bt.head_first || heads > 0, fn, "a head-first update needs a lower update of at least 3 x 3 tiles");
+            const int64_t tiles = (lower ? tm * (tm + 1) / 2 : tm * tn) - (heads ? 1 : 0);
             const int cus = (want < 256 ? want : 256) & ~7;     // one workgroup per compute unit (gfx950: 256), 8 XCDs
             const int64_t rounds = (tiles + cus - 1) / cus;
             int64_t g8 = (tiles + rounds - 1) / rounds;         // every workgroup busy in (nearly) every round ...
@@ -396,13 +443,14 @@ int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t 
             if (g8 > cus) g8 = cus;
             const dim3 grid((unsigned)g8);
 #define CIMRGP_PERS_LAUNCH(LOW_) \
-            hipLaunchKernelGGL((k_gemm_nt_pers<T, LOW_>), grid, dim3(PERS_THREADS), 0, st, c, ldc, a, lda, b, ldb, (int)tm, (int)tn, (int)tiles)
+            hipLaunchKernelGGL((k_gemm_nt_pers<T, LOW_>), grid, dim3(PERS_THREADS), 0, st, c, ldc, a, lda, b, ldb, (int)tm, (int)tn, (int)tiles, heads, bt.flag)
             if (lower) CIMRGP_PERS_LAUNCH(true); else CIMRGP_PERS_LAUNCH(false);
 #undef CIMRGP_PERS_LAUNCH
             CIMRGP_LAUNCH_CHECK(fn);
             return 0;
         }
     }
+    CIMRGP_REQUIRE(!bt.head_first, fn, "head-first update not eligible for the persistent kernel (gemm_pers_eligible)");
     if (t64 < 32) return gemm_launch<T, 1>(c, ldc, a, lda, b, ldb, m, n, k, lower, st, bt);
     if (t128 < 768) return gemm_launch<T, 2>(c, ldc, a, lda, b, ldb, m, n, k, lower, st, bt);
     return gemm_launch<T, 4>(c, ldc, a, lda, b, ldb, m, n, k, lower, st, bt);

@@ -1371,6 +1371,24 @@ void k_invT_step(T* __restrict__ invT, const T* __restrict__ L, int64_t ld, int 
     trsm64_body<T>(smem, Prow, CIMRGP_NB, TR, kw, SB * s, L + (int64_t)c0 * ld + k0, ld, inv64 + (int64_t)(c0 / SB) * (SB * SB));
 }
 
+// The panel chain's wait for the head tiles of a combined (head-first) persistent update: ONE workgroup polls the
+// count of stored head tiles (k_gemm_nt_pers adds 1 per tile behind an agent-scope release) and ends; the
+// chain's next launch follows it in queue order.  One resident wave cannot starve the update of compute
+// units (a poll inside the wide panel-solve launch could: its hundreds of workgroups would hold the units the
+// persistent workgroups are waiting for).  The poll is bounded (~seconds): on expiry the factorisation is
+// flagged as failed (info = INT_MAX) instead of hanging the device.
+__global__ void k_gate(const int* __restrict__ flag, int expected, int32_t* info)
+{
+    if (threadIdx.x == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
+            __builtin_amdgcn_s_sleep(64);
+            if (++spins > (1 << 24)) { atomicCAS(info, 0, 0x7fffffff); break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+}
+
 }  // namespace
 
 // One pass over the panels.  With FACTOR the matrix itself is factored; with
@@ -1579,9 +1597,8 @@ static int fused_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, T* 
 {
     const char* fn = "cimrgp_potrf";
     const bool rows = (b != nullptr && m > 0);
-    // share of FAR(prev) (+ NEAR) given to each of the five launches: their chain parts last about
-    // 17 / 22 / 27 / 31 / 12 us alone
-    static const double share[5] = {0.16, 0.20, 0.25, 0.28, 0.11};
+    // the chain parts of the five launches last about this long alone (us)
+    static const double chain_us[5] = {17.0, 22.0, 27.0, 31.0, 12.0};
     int64_t q0 = (prev_w > 0) ? k_begin - prev_w : -1;      // previous panel (-1: none)
     int64_t qw = prev_w;
     bool ph3_pending = false;                                // prev's last sub-block still owed to this panel's columns
@@ -1625,11 +1642,50 @@ static int fused_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, T* 
                 const int64_t near_tiles = tiles64(n - k1) * tiles64(wn);
                 const int64_t tf = (n > k2) ? tiles64(n - k2) : 0;
                 const int64_t far_tiles = tf * (tf + 1) / 2;
-                const double unit = (double)(near_tiles + far_tiles);
+                // How many of these K = 256 tiles each launch takes.  A launch's riders run in ROUNDS of
+                // (2 workgroups per compute unit - the launch's own chain workgroups), ~20 us per round of
+                // K = 256 tiles, and a launch lasts max(its chain part, its rounds): whole rounds are given
+                // to the launches whose chain part they lengthen least (a launch with 1.3 rounds of riders
+                // takes two rounds' time: the first version of this schedule, split by the chain parts'
+                // durations, took 221 us per panel at 4352 trailing rows where 7 packed rounds take ~150).
+                const int slots = 2 * 256;
+                const double t_round = 20.0;
+                const int64_t rows_below = n - k1;
+                int nchain_i[5], fixed_i[5];
+                for (int i = 0; i < 5; ++i) {
+                    // rows the launch's panel solve covers: below diagonal block i + 1 (links), below the panel (last solve)
+                    const int64_t below = (i == 4) ? rows_below : n - k0 - SB * (i + 1);
+                    nchain_i[i] = (i == 0) ? 1 : (int)((below + TR - 1) / TR) + (i < 4 ? 1 : 0) + (int)(((rows ? m : 0) + TR - 1) / TR);
+                    fixed_i[i] = 0;
+                }
+                // riders already placed (PH3, ROWS in launch 0; this panel's PH(p, s) go to launches 2..4: K = 64 tiles,
+                // about a third of a K = 256 tile each)
+                fixed_i[0] = rd[0].total / 3;
+                if (w == CIMRGP_NB) for (int i = 2; i < 5; ++i) fixed_i[i] = (int)(tiles64(n - k1) * tiles64(wn)) / 3;
+                int rounds[5] = {1, 1, 1, 1, 1};
+                auto capacity = [&](int i) { const int64_t c = (int64_t)rounds[i] * (slots - nchain_i[i]) - fixed_i[i]; return c > 0 ? c : 0; };
+                const int64_t need = near_tiles + far_tiles;
+                for (;;) {
+                    int64_t cap = 0;
+                    for (int i = 0; i < 5; ++i) cap += capacity(i);
+                    // NEAR must fit launches 0 and 1
+                    const bool near_ok = capacity(0) + capacity(1) >= near_tiles;
+                    if (cap >= need && near_ok) break;
+                    int best = -1;
+                    double best_cost = 1e30;
+                    for (int i = (near_ok ? 0 : 0); i < (near_ok ? 5 : 2); ++i) {
+                        const double now = (rounds[i] * t_round > chain_us[i]) ? rounds[i] * t_round : chain_us[i];
+                        const double then = ((rounds[i] + 1) * t_round > chain_us[i]) ? (rounds[i] + 1) * t_round : chain_us[i];
+                        const double cost = (then - now) / (double)(slots - nchain_i[i]);
+                        if (cost < best_cost - 1e-12) { best_cost = cost; best = i; }
+                    }
+                    ++rounds[best];
+                    if (rounds[best] > 64) break;           // cannot happen (guards the loop)
+                }
                 // NEAR(prev): launches 0 and 1 only (from launch 2 on this panel's sub-blocks update the same columns)
                 RiderJob<T> nr = rect_job(kmat + k1 * ld + k1, ld, pa + k1 * ld, ld, pa + k1 * ld, ld, n - k1, wn, qw);
-                int64_t near0 = (int64_t)(share[0] * unit);
-                if (near0 > near_tiles) near0 = near_tiles;
+                int64_t near0 = capacity(0) < near_tiles ? capacity(0) : near_tiles;
+                if (near_tiles - near0 > capacity(1)) near0 = near_tiles - capacity(1);     // (capacities cover it: near_ok)
                 RiderJob<T> n0 = nr; n0.first = 0; n0.count = (int)near0; add(0, n0);
                 RiderJob<T> n1 = nr; n1.first = (int)near0; n1.count = (int)(near_tiles - near0); add(1, n1);
                 if (far_tiles > 0) {
@@ -1638,7 +1694,7 @@ static int fused_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, T* 
                     fr.m = fr.n = (int)(n - k2); fr.k = (int)qw; fr.lower = 1; fr.tiles_n = (int)tf; fr.skip00 = 0; fr.rows_job = 0;
                     int64_t done = 0;
                     for (int i = 0; i < 5; ++i) {
-                        int64_t want = (int64_t)(share[i] * unit) - (i == 0 ? near0 : i == 1 ? (near_tiles - near0) : 0);
+                        int64_t want = capacity(i) - (i == 0 ? near0 : i == 1 ? (near_tiles - near0) : 0);
                         if (want < 0) want = 0;
                         if (i == 4 || want > far_tiles - done) want = far_tiles - done;
                         RiderJob<T> part = fr; part.first = (int)done; part.count = (int)want;
@@ -1686,6 +1742,7 @@ struct LookAhead {
     hipStream_t rows = nullptr;        // carried rows: lags behind the factorisation
     hipStream_t rows_far = nullptr;    // carried rows: far part of each panel's update (beside the rows' own panel chain)
     std::vector<hipEvent_t> ev;
+    int* flag = nullptr;               // device counter: head tiles stored by the combined update launches (k_gate polls it)
     hipStream_t owner = nullptr;       // the caller stream this context was created for
     std::mutex enqueue;                // one factorisation at a time enqueues on this context's queues
 };
@@ -1707,12 +1764,14 @@ LookAhead* make_ctx(int dev)
     // process exit in the profiler runs that crashed in an exit handler.  The persistent update kernel
     // splits the machine instead: a launch of G workgroups occupies G compute units.)
     if (ok) ok = hipStreamCreateWithPriority(&la->rows, hipStreamNonBlocking, lo) == hipSuccess;
+    if (ok) ok = hipMalloc(&la->flag, 64) == hipSuccess;
     // (the carried rows' second queue is created on first use: ensure_rows_far)
     if (!ok) {
         if (la->side) (void)hipStreamDestroy(la->side);
         if (la->bulk) (void)hipStreamDestroy(la->bulk);
         if (la->rows) (void)hipStreamDestroy(la->rows);
         if (la->rows_far) (void)hipStreamDestroy(la->rows_far);
+        if (la->flag) (void)hipFree(la->flag);
         delete la;
         return nullptr;
     }
@@ -1755,6 +1814,7 @@ int destroy_contexts()
             for (hipStream_t q : {la->side, la->bulk, la->rows, la->rows_far})
                 if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
             for (hipEvent_t e : la->ev) (void)hipEventDestroy(e);
+            if (la->flag) (void)hipFree(la->flag);
             delete la;
         }
         g_ctx[dev].clear();
@@ -1845,6 +1905,8 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     // update (and, off the chain, the carried rows).  Cross-stream edges: "panel final"
     // (side -> main, before the bulk update that reads it) and "bulk update done" (main -> side,
     // before the next head touches columns the bulk update wrote).
+    CIMRGP_HIP_TRY(hipMemsetAsync(la->flag, 0, sizeof(int), st), "hipMemsetAsync(flag)");
+    int flag_expected = 0;                             // head tiles the chain has been told to wait for so far
     hipEvent_t ev_start = la->ev[ne++];
     CIMRGP_HIP_TRY(hipEventRecord(ev_start, st), "hipEventRecord");
     CIMRGP_HIP_TRY(hipStreamWaitEvent(sp, ev_start, 0), "hipStreamWaitEvent");
@@ -1966,6 +2028,57 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
         hipEvent_t ev_go = ev_panel;                   // what the bulk stream waits for: panel k0 final ...
         const int64_t wn = (k1 < n) ? ((n - k1 < CIMRGP_NB) ? (n - k1) : CIMRGP_NB) : 0;   // next panel
         const int64_t k2 = k1 + wn;
+        // Round 3: head and bulk update of panel k0 as ONE persistent launch on the bulk queue.  Its first
+        // tiles are the next panel's columns (the old "head": on the chain's queue it ran on the few compute
+        // units the persistent bulk update leaves free -- 144 us for 1 Gflop at N = 8192, the longest link of
+        // the chain); they are counted as they are stored and the chain waits for the count through a
+        // one-workgroup gate kernel.  The next panel's first diagonal block does not wait: it takes its own
+        // 64 x 64 update as its prologue (as before) and the rest of the first 128 x 128 tile along as riders.
+        // (not while the carried rows are running: their kernels hold compute units the persistent workgroups
+        // of the combined launch -- head tiles included -- would have to wait for: 114 -> 109 posteriors/s)
+        const bool rows_running = rows && (n - k1 <= knobs().rows_start_below);
+        const int heads = (knobs().chain_mode == 0 && !rows_running && w == CIMRGP_NB && wn == CIMRGP_NB && n > k2 && !grp_open() &&
+                           group_size(n - k2 - ((n - k2 < CIMRGP_NB) ? (n - k2) : CIMRGP_NB), knobs().far_pair_above) == 1)
+                              ? gemm_pers_head_tiles(n - k1, (int)w, (int)sizeof(T)) : 0;
+        if (heads > 0) {
+            if (ev_rest) CIMRGP_HIP_TRY(hipStreamWaitEvent(sp, ev_rest, 0), "hipStreamWaitEvent");
+            // chain queue: first diagonal block (+ the rest of tile (0, 0) of 128 as riders), gate, the other links
+            Riders<T> r0 = no_riders<T>();
+            {
+                RiderJob<T>& jb = r0.job[0];
+                jb.c = k + k1 * ld + k1; jb.a = k + k1 * ld + k0; jb.b = k + k1 * ld + k0; jb.ldc = jb.lda = jb.ldb = ld;
+                jb.m = 128; jb.n = 128; jb.k = (int)w; jb.lower = 0; jb.tiles_n = 2; jb.first = 0; jb.count = 4; jb.skip00 = 1; jb.rows_job = 0;
+                r0.njobs = 1; r0.total = 4;
+            }
+            hipLaunchKernelGGL((k_diag64q<T>), dim3(1 + r0.total), dim3(Q_NT), 0, sp, k + k1 * ld + k1, ld, (int)SB,
+                               (const T*)(k + k1 * ld + k0), (int)w, ws + (k1 / SB) * (SB * SB), info, (int)k1, (int64_t)0, (int64_t)0,
+                               (int64_t)0, r0);
+            CIMRGP_LAUNCH_CHECK("cimrgp_potrf");
+            flag_expected += heads;
+            hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, sp, (const int*)la->flag, flag_expected, info);
+            CIMRGP_LAUNCH_CHECK("cimrgp_potrf");
+            rc = factor_panel<T>(k, n, ld, ws, info, k1, wn, sp, false, true);
+            if (rc) return rc;
+            hipEvent_t ev_next = la->ev[ne++];
+            CIMRGP_HIP_TRY(hipEventRecord(ev_next, sp), "hipEventRecord");
+            // bulk queue: everything right of panel k0, the next panel's columns first
+            CIMRGP_HIP_TRY(hipStreamWaitEvent(sb, ev_final, 0), "hipStreamWaitEvent");
+            const double mm = (double)(n - k1);
+            hipEvent_t rec = rec_open(sb, mm * (mm + 1.0) * (double)w);
+            GemmBatch gb = bulk_gb;
+            gb.head_first = 1;
+            gb.flag = la->flag;
+            rc = gemm_nt_sub<T>(k + k1 * ld + k1, ld, k + k1 * ld + k0, ld, k + k1 * ld + k0, ld, n - k1, n - k1, (int)w, true, sb, gb);
+            if (rec) (void)hipEventRecord(rec, sb);
+            if (rc) return rc;
+            ev_rest = la->ev[ne++];
+            CIMRGP_HIP_TRY(hipEventRecord(ev_rest, sb), "hipEventRecord");
+            ev_bulk_last = ev_rest;
+            ev_panel = ev_next;
+            rc = rows_after_panel(k0, k1, ev_final);
+            if (rc) return rc;
+            continue;
+        }
         if (k1 < n) {
             // chain: head (columns of the next panel, all rows below), then the next panel
             if (ev_rest) CIMRGP_HIP_TRY(hipStreamWaitEvent(sp, ev_rest, 0), "hipStreamWaitEvent");
