@@ -41,6 +41,8 @@ const Knobs& knobs()
         v.gemm_pers = (int)num("CIMRGP_GEMM_PERS", v.gemm_pers);
         v.pers_min_tiles = (int)num("CIMRGP_PERS_MIN_TILES", v.pers_min_tiles);
         v.chain_cus = (int)num("CIMRGP_CHAIN_CUS", v.chain_cus);
+        v.rows_fused_tail = (int)num("CIMRGP_ROWS_FUSED", v.rows_fused_tail);
+        v.rows_pair_above = num("CIMRGP_ROWS_PAIR", v.rows_pair_above);
 #endif
         return v;
     }();

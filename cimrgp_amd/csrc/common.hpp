@@ -114,6 +114,8 @@ struct Knobs {
     int fused_head0 = 1;                   // CIMRGP_HEAD0: first diagonal block of a panel takes its head update itself
     int gemm_pers = 256;                   // CIMRGP_GEMM_PERS: persistent trailing update on at most this many compute units (0: off)
     int pers_min_tiles = 512;              // CIMRGP_PERS_MIN_TILES: 128-tiles below which the tile-per-workgroup kernel is used
+    int rows_fused_tail = 0;               // CIMRGP_ROWS_FUSED: carried rows catch up at the tail switch, then ride in the chain's launches
+    int64_t rows_pair_above = 8192;        // CIMRGP_ROWS_PAIR: the carried rows' far updates take two panels at a time (K = 512) while more columns remain
     int chain_cus = 32;                    // CIMRGP_CHAIN_CUS: compute units the bulk update leaves to the panel chain (look-ahead phase)
 };
 const Knobs& knobs();

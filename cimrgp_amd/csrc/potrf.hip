@@ -84,7 +84,7 @@ constexpr int SB = 64;   // diagonal sub-block
 // (thresholds 2048..6144) raises the update kernel's rate (49 -> 56 % of peak) but not the
 // end-to-end time (longer-lived update workgroups, longer slot waits of the chain), so it
 // starts above that size.
-constexpr int64_t FAR_PAIR_ABOVE = 8192;          // (= Knobs::far_pair_above; the carried rows' grouping uses the constant)
+
 constexpr int64_t ROWS_PAIR_ABOVE_SOLVE = 1024;   // stand-alone row-wise solve: pair the updates while more columns remain
 
 // (the schedule's thresholds are `knobs()`, common.hpp: constants in the product build)
@@ -268,7 +268,7 @@ template <typename T> struct RiderJob {
     int skip00;                         // tile (0, 0) is left alone: the chain's workgroup 0 owns it
     int rows_job;                       // 1: c and a are carried rows (batch stride sb), 0: the matrix (stride sk)
 };
-constexpr int MAX_RIDER_JOBS = 4;
+constexpr int MAX_RIDER_JOBS = 6;
 template <typename T> struct Riders {
     RiderJob<T> job[MAX_RIDER_JOBS];
     int njobs;
@@ -1602,7 +1602,7 @@ static int fused_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, T* 
     int64_t q0 = (prev_w > 0) ? k_begin - prev_w : -1;      // previous panel (-1: none)
     int64_t qw = prev_w;
     bool ph3_pending = false;                                // prev's last sub-block still owed to this panel's columns
-    bool rows_pending = false;                               // ROWS(prev) owed (the tail entry never has carried rows)
+    bool rows_pending = false;                               // ROWS(prev) owed (at a tail entry the rows have seen prev already)
     auto tiles64 = [](int64_t v) { return (v + 63) / 64; };
     for (int64_t k0 = k_begin; k0 < n; k0 += CIMRGP_NB) {
         const int64_t w = (n - k0 < CIMRGP_NB) ? (n - k0) : CIMRGP_NB;
@@ -1633,10 +1633,15 @@ static int fused_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, T* 
                 jb.skip00 = 1;
                 add(0, jb);
             }
+            int64_t ph3_tiles = rd[0].total;                  // K = 64 tiles
+            int64_t rows_near_tiles = 0, rows_far_tiles = 0;
             if (rows_pending) {
-                RiderJob<T> jb = rect_job(b + k0, ldb, b + q0, ldb, pa + k0 * ld, ld, m, n - k0, qw);
+                // the carried rows' columns of THIS panel: needed by the panel's first link (which solves them)
+                RiderJob<T> jb = rect_job(b + k0, ldb, b + q0, ldb, pa + k0 * ld, ld, m, w, qw);
                 jb.rows_job = 1;
                 add(0, jb);
+                rows_near_tiles = jb.count;
+                if (wn > 0) rows_far_tiles = tiles64(m) * tiles64(n - k1);      // ... and everything right of it: any launch
             }
             if (wn > 0) {
                 const int64_t near_tiles = tiles64(n - k1) * tiles64(wn);
@@ -1660,11 +1665,11 @@ static int fused_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, T* 
                 }
                 // riders already placed (PH3, ROWS in launch 0; this panel's PH(p, s) go to launches 2..4: K = 64 tiles,
                 // about a third of a K = 256 tile each)
-                fixed_i[0] = rd[0].total / 3;
+                fixed_i[0] = (int)(ph3_tiles / 3 + rows_near_tiles);
                 if (w == CIMRGP_NB) for (int i = 2; i < 5; ++i) fixed_i[i] = (int)(tiles64(n - k1) * tiles64(wn)) / 3;
                 int rounds[5] = {1, 1, 1, 1, 1};
                 auto capacity = [&](int i) { const int64_t c = (int64_t)rounds[i] * (slots - nchain_i[i]) - fixed_i[i]; return c > 0 ? c : 0; };
-                const int64_t need = near_tiles + far_tiles;
+                const int64_t need = near_tiles + far_tiles + rows_far_tiles;
                 for (;;) {
                     int64_t cap = 0;
                     for (int i = 0; i < 5; ++i) cap += capacity(i);
@@ -1688,18 +1693,30 @@ static int fused_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, T* 
                 if (near_tiles - near0 > capacity(1)) near0 = near_tiles - capacity(1);     // (capacities cover it: near_ok)
                 RiderJob<T> n0 = nr; n0.first = 0; n0.count = (int)near0; add(0, n0);
                 RiderJob<T> n1 = nr; n1.first = (int)near0; n1.count = (int)(near_tiles - near0); add(1, n1);
-                if (far_tiles > 0) {
+                {
+                    // FAR(prev), then the carried rows' far update, over the launches' remaining capacities
                     RiderJob<T> fr;
                     fr.c = kmat + k2 * ld + k2; fr.a = pa + k2 * ld; fr.b = pa + k2 * ld; fr.ldc = fr.lda = fr.ldb = ld;
                     fr.m = fr.n = (int)(n - k2); fr.k = (int)qw; fr.lower = 1; fr.tiles_n = (int)tf; fr.skip00 = 0; fr.rows_job = 0;
-                    int64_t done = 0;
+                    fr.first = 0; fr.count = 0;
+                    RiderJob<T> rf = fr;
+                    if (rows_far_tiles > 0) {
+                        rf = rect_job(b + k1, ldb, b + q0, ldb, pa + k1 * ld, ld, m, n - k1, qw);
+                        rf.rows_job = 1;
+                    }
+                    int64_t done_f = 0, done_r = 0;
                     for (int i = 0; i < 5; ++i) {
-                        int64_t want = capacity(i) - (i == 0 ? near0 : i == 1 ? (near_tiles - near0) : 0);
-                        if (want < 0) want = 0;
-                        if (i == 4 || want > far_tiles - done) want = far_tiles - done;
-                        RiderJob<T> part = fr; part.first = (int)done; part.count = (int)want;
-                        add(i, part);
-                        done += want;
+                        int64_t room = capacity(i) - (i == 0 ? near0 : i == 1 ? (near_tiles - near0) : 0);
+                        if (room < 0) room = 0;
+                        int64_t take_f = far_tiles - done_f;
+                        if (i < 4 && take_f > room) take_f = room;
+                        room -= take_f;
+                        int64_t take_r = rows_far_tiles - done_r;
+                        if (i < 4 && take_r > room) take_r = (room > 0 ? room : 0);
+                        if (take_f > 0) { RiderJob<T> part = fr; part.first = (int)done_f; part.count = (int)take_f; add(i, part); }
+                        if (take_r > 0) { RiderJob<T> part = rf; part.first = (int)done_r; part.count = (int)take_r; add(i, part); }
+                        done_f += take_f;
+                        done_r += take_r;
                     }
                 }
             }
@@ -1949,22 +1966,26 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
         if (hipStreamCreateWithPriority(&la->rows_far, hipStreamNonBlocking, lo) != hipSuccess) la->rows_far = nullptr;
     }
     const bool rows_pipeline = (rows_queues() == 2) && la->rows_far != nullptr;
-    auto rows_after_panel = [&](int64_t k0, int64_t k1, hipEvent_t ev_final) -> int {
+    // Round 3 (knobs().rows_fused_tail): the carried rows do not start inside the look-ahead phase at all; at the
+    // switch to the one-queue tail they catch up with the whole machine to themselves (`force`), and from
+    // there on they ride in the chain's launches like the factorisation's own updates (fused_sweep).
+    const bool rows_fused = rows && knobs().rows_fused_tail != 0;
+    auto rows_after_panel = [&](int64_t k0, int64_t k1, hipEvent_t ev_final, bool force = false) -> int {
         if (!rows) return 0;
         hipStream_t sq = la->rows;                     // always present (make_ctx: all queues or no context)
         const int64_t rows_start_below = knobs().rows_start_below;
-        const bool defer = (n - k1 > rows_start_below) && (k1 < n);
-        if (defer) return 0;
+        const bool defer = rows_fused ? (k1 < n) : ((n - k1 > rows_start_below) && (k1 < n));
+        if (defer && !force) return 0;
         CIMRGP_HIP_TRY(hipStreamWaitEvent(sq, ev_final, 0), "hipStreamWaitEvent");
         // (pairing the rows' updates below that size was measured neutral-to-worse at N = 8192)
         for (int64_t r0 = rows_next; r0 <= k0; r0 += CIMRGP_NB) {
             const int64_t rw = (n - r0 < CIMRGP_NB) ? (n - r0) : CIMRGP_NB;
             const int64_t r1 = r0 + rw;
             const int64_t rn = (n - r1 < CIMRGP_NB) ? (n - r1) : CIMRGP_NB;
-            if (!rows_pipeline || rows_grp.g0 >= 0 || (n > r1 + rn && group_size(n - (r1 + rn), FAR_PAIR_ABOVE) > 1)) {
+            if (!rows_pipeline || rows_grp.g0 >= 0 || (n > r1 + rn && group_size(n - (r1 + rn), knobs().rows_pair_above) > 1)) {
                 // grouped far updates (large matrices): the rows' chain as one queue
                 if (ev_rows_far) { CIMRGP_HIP_TRY(hipStreamWaitEvent(sq, ev_rows_far, 0), "hipStreamWaitEvent"); ev_rows_far = nullptr; }
-                int rcr = rows_panel_step<T>(b, ldb, m, k, ld, n, ws, r0, rows_grp, FAR_PAIR_ABOVE, sq, "cimrgp_potrf_rows");
+                int rcr = rows_panel_step<T>(b, ldb, m, k, ld, n, ws, r0, rows_grp, knobs().rows_pair_above, sq, "cimrgp_potrf_rows");
                 if (rcr) return rcr;
                 continue;
             }
@@ -1998,7 +2019,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     for (int64_t k0 = 0; k0 < n; k0 += CIMRGP_NB) {
         const int64_t w  = (n - k0 < CIMRGP_NB) ? (n - k0) : CIMRGP_NB;
         const int64_t k1 = k0 + w;
-        if (!rows && k1 < n && n - k1 <= single_tail_below && !grp_open()) {
+        if ((!rows || rows_fused) && k1 < n && n - k1 <= single_tail_below && !grp_open()) {
             // ---- single-stream tail.  Once the trailing matrix is small the look-ahead no longer
             // pays: its chain kernels wait for slots beside the update and every panel costs an
             // inter-queue hop, while one queue runs 4 x (diag + solve) = 124 us plus ONE update of
@@ -2010,15 +2031,25 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
             // panels' updates once the bulk queue has drained.
             CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0), "hipStreamWaitEvent");
             if (sb != st && ev_bulk_last) CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_bulk_last, 0), "hipStreamWaitEvent");
-            // (this branch is taken without carried rows only)  Round 3: the tail is the fused one-queue sweep --
-            // the head update of panel k0 (the next panel's columns, all rows) in a launch of its own, everything
-            // after it rides in the chains' launches (fused_sweep).
+            // Round 3: the tail is the fused one-queue sweep -- the head update of panel k0 (the next panel's
+            // columns, all rows) in a launch of its own, everything after it rides in the chains' launches
+            // (fused_sweep).  Carried rows first catch up with every panel up to k0 on their own queues
+            // (the factorisation would be starved of compute units by their large updates anyway: it stood
+            // still for ~2 ms of the round-2 schedule), then ride along.
+            if (rows) {
+                rc = rows_after_panel(k0, k1, ev_panel, true);
+                if (rc) return rc;
+                if (ev_rows_far) { CIMRGP_HIP_TRY(hipStreamWaitEvent(la->rows, ev_rows_far, 0), "hipStreamWaitEvent"); ev_rows_far = nullptr; }
+                hipEvent_t ev_caught = la->ev[ne++];
+                CIMRGP_HIP_TRY(hipEventRecord(ev_caught, la->rows), "hipEventRecord");
+                CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_caught, 0), "hipStreamWaitEvent");
+            }
             {
                 const int64_t kn = k1 + ((n - k1 < CIMRGP_NB) ? (n - k1) : CIMRGP_NB);
                 rc = gemm_nt_sub<T>(k + k1 * ld + k1, ld, k + k1 * ld + k0, ld, k + k1 * ld + k0, ld,
                                     n - k1, kn - k1, (int)w, false, st);
                 if (rc) return rc;
-                rc = fused_sweep<T>(k, n, ld, ws, info, (T*)nullptr, 0, 0, PotrfBatch(), st, k1, w);
+                rc = fused_sweep<T>(k, n, ld, ws, info, rows ? b : (T*)nullptr, rows ? m : 0, rows ? ldb : 0, PotrfBatch(), st, k1, w);
                 if (rc) return rc;
             }
             tail_done = true;
@@ -2036,7 +2067,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
         // 64 x 64 update as its prologue (as before) and the rest of the first 128 x 128 tile along as riders.
         // (not while the carried rows are running: their kernels hold compute units the persistent workgroups
         // of the combined launch -- head tiles included -- would have to wait for: 114 -> 109 posteriors/s)
-        const bool rows_running = rows && (n - k1 <= knobs().rows_start_below);
+        const bool rows_running = rows && !rows_fused && (n - k1 <= knobs().rows_start_below);
         const int heads = (knobs().chain_mode == 0 && !rows_running && w == CIMRGP_NB && wn == CIMRGP_NB && n > k2 && !grp_open() &&
                            group_size(n - k2 - ((n - k2 < CIMRGP_NB) ? (n - k2) : CIMRGP_NB), knobs().far_pair_above) == 1)
                               ? gemm_pers_head_tiles(n - k1, (int)w, (int)sizeof(T)) : 0;
