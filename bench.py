@@ -37,6 +37,18 @@ FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32-input MFMA peak
 
 import workloads
 
+PMC_PROFILE = "r03_pmc_bench_n8192.json"
+
+
+def _sources_sha():
+    """sha256 over the kernel sources the committed PMC profile describes (tools/make_pmc_profile.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("common.hpp", "gemm_tile.hpp", "gemm_nt.hip", "potrf.hip", "gram.hip"):
+        with open(os.path.join(ROOT, "cimrgp_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
 
 def make_block(n, q, seed):
     """SURVEY.md 8d config 2 (workloads.make_block): x ~ sorted U(-sqrt3, sqrt3),
@@ -369,9 +381,9 @@ def main():
         # stage times are read after the loop from the last step's events only
     barrier()
     dt = time.perf_counter() - t0
-    tr_ms, tr_fl, tr_cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
-    _lib.check(lib.cimrgp_profile_collect(ctypes.byref(tr_ms), ctypes.byref(tr_fl), ctypes.byref(tr_cnt)),
-               "cimrgp_profile_collect")
+    tr_ms, tr_fl, tr_by, tr_cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+    _lib.check(lib.cimrgp_profile_collect_bytes(ctypes.byref(tr_ms), ctypes.byref(tr_fl), ctypes.byref(tr_by), ctypes.byref(tr_cnt)),
+               "cimrgp_profile_collect_bytes")
     for i in range(5):
         stage_ms[i] = ev[i].elapsed_time(ev[i + 1])
     last_mean = mean.double().cpu().numpy()                    # the last timed step's outputs (this rank)
@@ -422,29 +434,36 @@ def main():
                          "potrf_with_carried_rows": stage_ms[2], "backward_solve_and_predict": stage_ms[3],
                          "reduce": stage_ms[4], "potrf_alone": chol_ms},
             "gram_gbps_lower": (n * (n + 1) / 2 * (8 if args.dtype == "f64" else 4)) / (stage_ms[0] * 1e-3) / 1e9,
-            "roofline": {"bound": "mfma", "kernel": "k_gemm_nt_sub<%s, lower> (Cholesky trailing update)"
-                                                    % ("double" if args.dtype == "f64" else "float"),
+            "roofline": {"bound": "mfma", "kernel": "lower trailing updates of cimrgp_potrf: k_gemm_nt_pers<%s, lower> (look-ahead phase: head + bulk in "
+                                                    "one persistent launch) and k_gemm_nt_sub<%s, lower, *>"
+                                                    % (("double", "double") if args.dtype == "f64" else ("float", "float")),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "launches": int(tr_cnt.value),
                          "avg_launch_ms": tr_ms.value / max(1, tr_cnt.value),
                          "avg_launch_gflop": tr_fl.value / max(1, tr_cnt.value) / 1e9,
                          "traffic": None},
         }
-        # HBM traffic and matrix-core busy fraction of that kernel, and the Gram builder's written
-        # bytes, come from the committed rocprofv3 --pmc passes of this same command (counters cannot
-        # be collected from inside the process being timed): profiles/r02b_pmc_bench_n8192.json
-        pmc = os.path.join(ROOT, "profiles", "r02b_pmc_bench_n8192.json")
+        # HBM traffic and matrix-core busy fraction of that kernel, and the Gram builder's written bytes, come from
+        # committed rocprofv3 --pmc passes of this same command (counters cannot be collected from inside the process
+        # being timed).  The profile names the source hash it was collected from: when the kernels have changed
+        # since, the counters are reported as stale under `from_profile` and NOT put into the roofline.
+        out["roofline"]["algorithmic_bytes_per_launch"] = tr_by.value / max(1, tr_cnt.value)
+        pmc = os.path.join(ROOT, "profiles", PMC_PROFILE)
         if args.dtype == "f64" and n == 8192 and os.path.exists(pmc):
             with open(pmc) as fh:
                 pj = json.load(fh)
-            out["roofline"]["traffic"] = pj["trailing_update"]["traffic_bytes_per_launch"]
-            out["roofline"]["traffic_unit"] = ("bytes/launch (PMC upper bound: 2*FETCH_SIZE + WRITE_SIZE, separate passes, "
-                                               "profiles/r02b_pmc_bench_n8192.json)")
-            mm = [n - 256 * (p + 2) for p in range((n // 256) - 2)]
-            out["roofline"]["algorithmic_bytes_per_launch"] = float(np.mean([m * (m + 1) / 2 * 8 * 2 + m * 256 * 8 for m in mm]))
-            out["roofline"]["mfma_busy_frac_pmc"] = pj["trailing_update_mfma"]["mfma_busy_frac"]
-            out["gram_hbm_write_gbps_rocprof"] = pj["gram"]["hbm_write_GBps_rocprof"]
-            out["gram_frac_of_hbm_peak"] = pj["gram"]["frac_of_8TBps"]
+            fresh = pj.get("sources_sha256") == _sources_sha()
+            fp = {"file": "profiles/" + PMC_PROFILE, "commit": pj.get("commit"), "sources_sha256": pj.get("sources_sha256"),
+                  "matches_this_code": fresh,
+                  "traffic_bytes_per_launch": pj.get("trailing_update", {}).get("traffic_bytes_per_launch"),
+                  "mfma_busy_frac_pmc": pj.get("trailing_update_mfma", {}).get("mfma_busy_frac"),
+                  "gram_hbm_write_gbps_rocprof": pj.get("gram", {}).get("hbm_write_GBps_rocprof"),
+                  "gram_frac_of_hbm_peak": pj.get("gram", {}).get("frac_of_8TBps")}
+            out["from_profile"] = fp
+            if fresh:
+                out["roofline"]["traffic"] = fp["traffic_bytes_per_launch"]
+                out["roofline"]["traffic_unit"] = ("bytes/launch (PMC upper bound: 2*FETCH_SIZE + WRITE_SIZE, separate passes; "
+                                                   "%s, commit %s)" % (fp["file"], fp["commit"]))
         if world == 1 and not args.no_cpu_baseline:
             rec, omean, ovar = cpu_baseline(n, ns, q, ell, sf2, noise, 1234, args.cpu_warmups, args.cpu_repeats)
             out["cpu_baseline"] = rec

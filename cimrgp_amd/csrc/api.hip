@@ -43,6 +43,7 @@ const Knobs& knobs()
         v.chain_cus = (int)num("CIMRGP_CHAIN_CUS", v.chain_cus);
         v.rows_fused_tail = (int)num("CIMRGP_ROWS_FUSED", v.rows_fused_tail);
         v.rows_pair_above = num("CIMRGP_ROWS_PAIR", v.rows_pair_above);
+        v.fused_max_chain_wgs = num("CIMRGP_FUSED_MAX", v.fused_max_chain_wgs);
 #endif
         return v;
     }();
@@ -525,6 +526,11 @@ int cimrgp_profile_begin(void) { return profile_begin(); }
 int cimrgp_profile_collect(double* total_ms, double* total_flops, int64_t* launches)
 {
     return profile_collect(total_ms, total_flops, launches);
+}
+
+int cimrgp_profile_collect_bytes(double* total_ms, double* total_flops, double* total_bytes, int64_t* launches)
+{
+    return profile_collect(total_ms, total_flops, launches, total_bytes);
 }
 
 }  // extern "C"

@@ -116,6 +116,7 @@ struct Knobs {
     int pers_min_tiles = 512;              // CIMRGP_PERS_MIN_TILES: 128-tiles below which the tile-per-workgroup kernel is used
     int rows_fused_tail = 0;               // CIMRGP_ROWS_FUSED: carried rows catch up at the tail switch, then ride in the chain's launches
     int64_t rows_pair_above = 8192;        // CIMRGP_ROWS_PAIR: the carried rows' far updates take two panels at a time (K = 512) while more columns remain
+    int64_t fused_max_chain_wgs = 768;     // CIMRGP_FUSED_MAX: one-queue sweeps ride their updates in the chain's launches while batch x n / 32 is at most this
     int chain_cus = 32;                    // CIMRGP_CHAIN_CUS: compute units the bulk update leaves to the panel chain (look-ahead phase)
 };
 const Knobs& knobs();
@@ -134,7 +135,7 @@ template <typename T> int solve_rows_run(const T* l, int64_t n, int64_t ld, cons
                                          int64_t ldb, hipStream_t st, PotrfBatch bt = PotrfBatch());
 int potrf_shutdown();     // destroys the look-ahead contexts (streams, events): cimrgp_shutdown
 int profile_begin();
-int profile_collect(double* total_ms, double* total_flops, int64_t* launches);
+int profile_collect(double* total_ms, double* total_flops, int64_t* launches, double* total_bytes = nullptr);
 // gemm_nt.hip
 // A batch of independent products in one launch (equal shapes; element strides between problems).
 // skip_first: the first 64 x 64 tile of a rectangular update is left alone (the chain has already

@@ -402,7 +402,8 @@ bool gemm_uses_tile64(int64_t m, int64_t n, bool lower, int count)
 {
     const int64_t t128 = ((m + 127) / 128) * ((n + 127) / 128) / (lower ? 2 : 1) * count;
     const int64_t t64 = ((m + 63) / 64) * ((n + 63) / 64) / (lower ? 2 : 1) * count;
-    return !lower && t64 >= 32 && t128 < 768;
+    const int64_t thin = (m < n) ? m : n;
+    return !lower && t64 >= 32 && thin > 32 && (t128 < 768 || thin <= 64);
 }
 
 template <typename T>
@@ -451,8 +452,12 @@ int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t 
         }
     }
     CIMRGP_REQUIRE(!bt.head_first, fn, "head-first update not eligible for the persistent kernel (gemm_pers_eligible)");
+    // a thin C (the q carried target rows of a batched fit: m = 2) must not be padded to 128-row tiles: a batch of
+    // 128 such updates used 128 x 128 tiles for 2 rows each and took a quarter of a fine layer's fit time
+    const int64_t thin = (m < n) ? m : n;
+    if (!bt.skip_first && thin <= 32) return gemm_launch<T, 1>(c, ldc, a, lda, b, ldb, m, n, k, lower, st, bt);
     if (t64 < 32) return gemm_launch<T, 1>(c, ldc, a, lda, b, ldb, m, n, k, lower, st, bt);
-    if (t128 < 768) return gemm_launch<T, 2>(c, ldc, a, lda, b, ldb, m, n, k, lower, st, bt);
+    if (t128 < 768 || thin <= 64) return gemm_launch<T, 2>(c, ldc, a, lda, b, ldb, m, n, k, lower, st, bt);
     return gemm_launch<T, 4>(c, ldc, a, lda, b, ldb, m, n, k, lower, st, bt);
 }
 

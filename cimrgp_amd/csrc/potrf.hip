@@ -23,7 +23,7 @@ namespace cimrgp {
 // Events are recorded on the launch stream around every lower-triangular
 // trailing-update launch while profiling is on; collect() waits for them.
 namespace {
-struct TrailRec { hipEvent_t start, stop; double flops; };
+struct TrailRec { hipEvent_t start, stop; double flops, bytes; };
 std::vector<TrailRec> g_recs;
 std::vector<TrailRec> g_free;
 bool g_profile = false;
@@ -37,10 +37,10 @@ int profile_begin()
     return 0;
 }
 
-int profile_collect(double* total_ms, double* total_flops, int64_t* launches)
+int profile_collect(double* total_ms, double* total_flops, int64_t* launches, double* total_bytes)
 {
     std::lock_guard<std::mutex> guard(g_profile_mutex);
-    double ms = 0.0, fl = 0.0;
+    double ms = 0.0, fl = 0.0, by = 0.0;
     int64_t cnt = 0;
     for (auto& r : g_recs) {
         hipError_t e = hipEventSynchronize(r.stop);
@@ -48,20 +48,22 @@ int profile_collect(double* total_ms, double* total_flops, int64_t* launches)
         float t = 0.f;
         e = hipEventElapsedTime(&t, r.start, r.stop);
         if (e != hipSuccess) return check_hip(e, "cimrgp_profile_collect", "hipEventElapsedTime");
-        ms += t; fl += r.flops; ++cnt;
+        ms += t; fl += r.flops; by += r.bytes; ++cnt;
         g_free.push_back(r);
     }
     g_recs.clear();
     g_profile = false;
     if (total_ms) *total_ms = ms;
     if (total_flops) *total_flops = fl;
+    if (total_bytes) *total_bytes = by;
     if (launches) *launches = cnt;
     return 0;
 }
 
 // Opens a record (start event on `st`) and returns its stop event, to be recorded behind the launch;
 // nullptr when profiling is off.
-static hipEvent_t rec_open(hipStream_t st, double flops)
+// flops = M (M + 1) K of a lower update; bytes = its algorithmic traffic: C (lower) read and written, the panel once
+static hipEvent_t rec_open(hipStream_t st, double flops, double bytes = 0.0)
 {
     std::lock_guard<std::mutex> guard(g_profile_mutex);
     if (!g_profile) return nullptr;
@@ -71,6 +73,7 @@ static hipEvent_t rec_open(hipStream_t st, double flops)
         if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return nullptr;
     }
     r.flops = flops;
+    r.bytes = bytes;
     (void)hipEventRecord(r.start, st);
     g_recs.push_back(r);
     return r.stop;
@@ -1553,7 +1556,7 @@ static int panel_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info,
         if (n > k1) {
             if (FACTOR) {
                 const double mm = (double)(n - k1);
-                hipEvent_t rec = rec_open(st, mm * (mm + 1.0) * (double)w * (double)bt.count);   // lower SYRK: M(M+1)K flop
+                hipEvent_t rec = rec_open(st, mm * (mm + 1.0) * (double)w * (double)bt.count, (mm * (mm + 1.0) + mm * (double)w) * (double)sizeof(T) * (double)bt.count);   // lower SYRK: M(M+1)K flop
                 GemmBatch gb; gb.count = bt.count; gb.sc = gb.sa = gb.sb = bt.sk;
                 int rc = gemm_nt_sub<T>(kmat + k1 * ld + k1, ld, kmat + k1 * ld + k0, ld,
                                         kmat + k1 * ld + k0, ld, n - k1, n - k1, (int)w, true, st, gb);
@@ -2095,7 +2098,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
             // bulk queue: everything right of panel k0, the next panel's columns first
             CIMRGP_HIP_TRY(hipStreamWaitEvent(sb, ev_final, 0), "hipStreamWaitEvent");
             const double mm = (double)(n - k1);
-            hipEvent_t rec = rec_open(sb, mm * (mm + 1.0) * (double)w);
+            hipEvent_t rec = rec_open(sb, mm * (mm + 1.0) * (double)w, (mm * (mm + 1.0) + mm * (double)w) * (double)sizeof(T));
             GemmBatch gb = bulk_gb;
             gb.head_first = 1;
             gb.flag = la->flag;
@@ -2181,7 +2184,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
                         // which overlaps the chain's next panels
                         if (n > k3) {
                             const double mm = (double)(n - k3);
-                            hipEvent_t rec = rec_open(sb, mm * (mm + 1.0) * (double)kk);
+                            hipEvent_t rec = rec_open(sb, mm * (mm + 1.0) * (double)kk, (mm * (mm + 1.0) + mm * (double)kk) * (double)sizeof(T));
                             rc = gemm_nt_sub<T>(k + k3 * ld + k3, ld, k + k3 * ld + grp.g0, ld, k + k3 * ld + grp.g0, ld,
                                                 n - k3, n - k3, kk, true, sb, bulk_gb);
                             if (rec) (void)hipEventRecord(rec, sb);
@@ -2193,7 +2196,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
                     }
                 } else {
                     const double mm = (double)(n - k2);
-                    hipEvent_t rec = rec_open(sb, mm * (mm + 1.0) * (double)w);
+                    hipEvent_t rec = rec_open(sb, mm * (mm + 1.0) * (double)w, (mm * (mm + 1.0) + mm * (double)w) * (double)sizeof(T));
                     rc = gemm_nt_sub<T>(k + k2 * ld + k2, ld, k + k2 * ld + k0, ld, k + k2 * ld + k0, ld,
                                         n - k2, n - k2, (int)w, true, sb, bulk_gb);
                     if (rec) (void)hipEventRecord(rec, sb);
@@ -2233,7 +2236,10 @@ int potrf_batched_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, i
     if (bt.count < 1 || bt.count >= 65536) return fail("cimrgp_potrf_batched", "batch count out of range");
     hipError_t e = hipMemsetAsync(info, 0, sizeof(int32_t) * (size_t)bt.count, st);
     if (e != hipSuccess) return check_hip(e, "cimrgp_potrf_batched", "hipMemsetAsync(info)");
-    int rc = fused_sweep<T>(k, n, ld, ws, info, b, m, ldb, bt, st);
+    // A big batch fills the machine with its panel solves already: the updates then keep launches of their own
+    // (128-tiles, more efficient than 64-tile riders); riders pay where the chain's launches leave units idle.
+    const bool ride = (int64_t)bt.count * (n / TR) <= knobs().fused_max_chain_wgs;
+    int rc = ride ? fused_sweep<T>(k, n, ld, ws, info, b, m, ldb, bt, st) : panel_sweep<T, true>(k, n, ld, ws, info, b, m, ldb, st, bt);
     return rc ? rc : build_invT<T>(k, n, ld, ws, st, bt);
 }
 

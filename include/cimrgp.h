@@ -306,6 +306,10 @@ int cimrgp_shutdown(void);
  * HOST pointers.  Not thread-safe; meant for one benchmarking thread. */
 int cimrgp_profile_begin(void);
 int cimrgp_profile_collect(double* total_ms, double* total_flops, int64_t* launches);
+/* the same, plus the summed ALGORITHMIC bytes of those launches: C (lower triangle) read and written
+ * once, the K-wide panel read once -- (M (M + 1) + M K) x element size per launch. */
+int cimrgp_profile_collect_bytes(double* total_ms, double* total_flops, double* total_bytes,
+                                 int64_t* launches);
 
 #ifdef __cplusplus
 }
