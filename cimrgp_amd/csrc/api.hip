@@ -44,6 +44,7 @@ const Knobs& knobs()
         v.rows_fused_tail = (int)num("CIMRGP_ROWS_FUSED", v.rows_fused_tail);
         v.rows_pair_above = num("CIMRGP_ROWS_PAIR", v.rows_pair_above);
         v.fused_max_chain_wgs = num("CIMRGP_FUSED_MAX", v.fused_max_chain_wgs);
+        v.rows_cus = (int)num("CIMRGP_ROWS_CUS", v.rows_cus);
 #endif
         return v;
     }();

@@ -108,7 +108,7 @@ template <> __device__ __forceinline__ uint4 neg_chunk<float>(uint4 v)
 struct Knobs {
     int chain_mode = 0;                    // CIMRGP_CHAIN = split | wide | quad: 1 round-1 links / 2 nine-wave / 3 four-wave (0: by context)
     int64_t tail_below = 4864;             // CIMRGP_TAIL_BELOW: trailing matrix at or below this: finish on one queue
-    int64_t rows_start_below = 4608;       // CIMRGP_ROWS_START: carried rows start once the trailing matrix is smaller
+    int64_t rows_start_below = 6144;       // CIMRGP_ROWS_START: carried rows start once the trailing matrix is smaller
     int64_t head_first_above = 1ll << 30;  // CIMRGP_HEAD_FIRST: bulk update waits for the head above this (off)
     int64_t far_pair_above = 8192;         // CIMRGP_FAR_PAIR: far part updated once per group of panels above this
     int fused_head0 = 1;                   // CIMRGP_HEAD0: first diagonal block of a panel takes its head update itself
@@ -117,6 +117,7 @@ struct Knobs {
     int rows_fused_tail = 0;               // CIMRGP_ROWS_FUSED: carried rows catch up at the tail switch, then ride in the chain's launches
     int64_t rows_pair_above = 8192;        // CIMRGP_ROWS_PAIR: the carried rows' far updates take two panels at a time (K = 512) while more columns remain
     int64_t fused_max_chain_wgs = 768;     // CIMRGP_FUSED_MAX: one-queue sweeps ride their updates in the chain's launches while batch x n / 32 is at most this
+    int rows_cus = 192;                    // CIMRGP_ROWS_CUS: compute units of the carried rows' far updates (persistent kernel; 0: tile-per-workgroup kernel)
     int chain_cus = 32;                    // CIMRGP_CHAIN_CUS: compute units the bulk update leaves to the panel chain (look-ahead phase)
 };
 const Knobs& knobs();
@@ -142,7 +143,7 @@ int profile_collect(double* total_ms, double* total_flops, int64_t* launches, do
 // replaced it by its factor; only honoured when the launch uses 64-tiles: gemm_uses_tile64)
 // pers: compute units for the persistent form of the update (-1: knobs().gemm_pers, 0: never)
 // head_first + flag: the look-ahead's combined head + bulk update as one persistent launch (gemm_nt.hip)
-struct GemmBatch { int count = 1; int64_t sc = 0, sa = 0, sb = 0; int skip_first = 0; int pers = -1; int head_first = 0; int* flag = nullptr; };
+struct GemmBatch { int count = 1; int64_t sc = 0, sa = 0, sb = 0; int skip_first = 0; int pers = -1; int head_first = 0; int* flag = nullptr; int pers_force = 0; };
 bool gemm_uses_tile64(int64_t m, int64_t n, bool lower, int count = 1);
 int gemm_pers_head_tiles(int64_t m, int k, int elem_bytes);
 template <typename T> int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t ldb,

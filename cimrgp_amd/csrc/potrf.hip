@@ -2010,7 +2010,23 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
             if (n > r1 + rn) {
                 hipStream_t sf = la->rows_far;
                 CIMRGP_HIP_TRY(hipStreamWaitEvent(sf, ev_w, 0), "hipStreamWaitEvent");
-                rcr = gemm_nt_sub<T>(b + r1 + rn, ldb, b + r0, ldb, k + (r1 + rn) * ld + r0, ld, m, n - (r1 + rn), (int)rw, false, sf);
+                // The far update: whole 128-row tiles of the rows on the persistent kernel within a budget of compute
+                // units (it then cannot crowd the factorisation out of the machine the way a 1000-workgroup launch of
+                // the tile-per-workgroup kernel does), the few rows left over (the q target rows) in a thin launch.
+                const int64_t m128 = (knobs().rows_cus >= 8 && knobs().gemm_pers >= 8) ? (m / 128) * 128 : 0;
+                const int64_t nfar = n - (r1 + rn);
+                if (m128 >= 128 && nfar % 128 == 0 && (m128 / 128) * (nfar / 128) >= 2 * knobs().rows_cus) {
+                    GemmBatch gb; gb.pers = knobs().rows_cus; gb.pers_force = 1;
+                    rcr = gemm_nt_sub<T>(b + r1 + rn, ldb, b + r0, ldb, k + (r1 + rn) * ld + r0, ld, m128, nfar, (int)rw, false, sf, gb);
+                    if (rcr) return rcr;
+                    if (m > m128) {
+                        GemmBatch g0; g0.pers = 0;
+                        rcr = gemm_nt_sub<T>(b + m128 * ldb + r1 + rn, ldb, b + m128 * ldb + r0, ldb, k + (r1 + rn) * ld + r0, ld,
+                                             m - m128, nfar, (int)rw, false, sf, g0);
+                    }
+                } else {
+                    rcr = gemm_nt_sub<T>(b + r1 + rn, ldb, b + r0, ldb, k + (r1 + rn) * ld + r0, ld, m, nfar, (int)rw, false, sf);
+                }
                 if (rcr) return rcr;
                 ev_rows_far = la->ev[ne++];
                 CIMRGP_HIP_TRY(hipEventRecord(ev_rows_far, sf), "hipEventRecord");
