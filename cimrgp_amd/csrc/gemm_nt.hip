@@ -431,7 +431,7 @@ int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t 
         const int want = (bt.pers >= 0) ? bt.pers : knobs().gemm_pers;
         const int nkt = (k % bke) ? 0 : k / bke;
         if (want >= 8 && nkt == PERS_STAGES && bt.count == 1 && !bt.skip_first && m % 128 == 0 && n % 128 == 0 &&
-            ldc < (1ll << 23) && lda < (1ll << 23) && ldb < (1ll << 23) && (t128 >= knobs().pers_min_tiles || bt.head_first)) {
+            ldc < (1ll << 23) && lda < (1ll << 23) && ldb < (1ll << 23) && (t128 >= knobs().pers_min_tiles || bt.head_first || bt.pers_force)) {
             const int64_t tm = m / 128, tn = n / 128;
             // head-first launch (the look-ahead's combined head + bulk update): tile (0, 0) is left to the chain
             const int heads = (bt.head_first && lower && tm >= 3) ? (int)(2 * tm - 2) : 0;

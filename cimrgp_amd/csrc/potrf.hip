@@ -1594,12 +1594,33 @@ static int panel_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info,
 // `prev_w` > 0: the sweep starts behind a final panel [k_begin - prev_w, k_begin) whose contribution has been
 // applied to panel k_begin's columns ONLY (the tail of a look-ahead factorisation, after its last head update).
 // ---------------------------------------------------------------------------
+// Optional second queue of a fused sweep: while FAR(prev) is large the riders cannot hide it (the first panels of
+// a tail were rider-bound: 225 us per panel at 4352 trailing rows against a chain of ~115), so it runs as a
+// persistent launch on `bulk` within `cus` compute units, beside the chain on the others.  FAR(prev) touches
+// columns from k2 on only, the chain of panel p and its riders (PH3, NEAR, PH) the columns before k2: nothing
+// else to order than "FAR of the panel before last is done" before a chain starts and "prev is final" before a FAR.
+struct FarBulk {
+    hipStream_t bulk = nullptr;
+    std::vector<hipEvent_t>* ev = nullptr;
+    size_t* ne = nullptr;
+    int cus = 0;
+    int64_t min_rows = 1 << 30;          // FAR on the bulk queue while n - k2 >= min_rows
+};
+
 template <typename T>
 static int fused_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m, int64_t ldb,
-                       PotrfBatch bt, hipStream_t st, int64_t k_begin = 0, int64_t prev_w = 0)
+                       PotrfBatch bt, hipStream_t st, int64_t k_begin = 0, int64_t prev_w = 0, const FarBulk* fb = nullptr)
 {
     const char* fn = "cimrgp_potrf";
     const bool rows = (b != nullptr && m > 0);
+    hipEvent_t ev_prev_final = nullptr;                     // (far-bulk mode) panel `prev` is final, on st
+    hipEvent_t ev_far_last = nullptr;                       // (far-bulk mode) the last FAR launched on the bulk queue
+    auto next_event = [&]() { return (*fb->ev)[(*fb->ne)++]; };
+    if (fb && prev_w > 0) {
+        ev_prev_final = next_event();
+        hipError_t e = hipEventRecord(ev_prev_final, st);
+        if (e != hipSuccess) return check_hip(e, fn, "hipEventRecord");
+    }
     // the chain parts of the five launches last about this long alone (us)
     static const double chain_us[5] = {17.0, 22.0, 27.0, 31.0, 12.0};
     int64_t q0 = (prev_w > 0) ? k_begin - prev_w : -1;      // previous panel (-1: none)
@@ -1614,6 +1635,7 @@ static int fused_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, T* 
         const int64_t k2 = k1 + wn;
         Riders<T> rd[5];
         for (int i = 0; i < 5; ++i) rd[i] = no_riders<T>();
+        bool far_launched = false;
         auto add = [&](int launch, const RiderJob<T>& jb) {
             if (jb.count <= 0) return;
             Riders<T>& r = rd[launch];
@@ -1649,14 +1671,28 @@ static int fused_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, T* 
             if (wn > 0) {
                 const int64_t near_tiles = tiles64(n - k1) * tiles64(wn);
                 const int64_t tf = (n > k2) ? tiles64(n - k2) : 0;
-                const int64_t far_tiles = tf * (tf + 1) / 2;
+                // FAR(prev) on the bulk queue (persistent, fb->cus units) while it is large; as riders otherwise
+                const bool far_on_bulk = fb && ev_prev_final && bt.count == 1 && n - k2 >= fb->min_rows && (n - k2) % 128 == 0 &&
+                                         qw == CIMRGP_NB && gemm_pers_head_tiles(n - k2, (int)qw, (int)sizeof(T)) > 0;
+                if (far_on_bulk) {
+                    hipError_t e = hipStreamWaitEvent(fb->bulk, ev_prev_final, 0);
+                    if (e != hipSuccess) return check_hip(e, fn, "hipStreamWaitEvent");
+                    GemmBatch gb; gb.pers = fb->cus; gb.pers_force = 1;
+                    const double mm = (double)(n - k2);
+                    hipEvent_t rec = rec_open(fb->bulk, mm * (mm + 1.0) * (double)qw, (mm * (mm + 1.0) + mm * (double)qw) * (double)sizeof(T));
+                    int rcf = gemm_nt_sub<T>(kmat + k2 * ld + k2, ld, pa + k2 * ld, ld, pa + k2 * ld, ld, n - k2, n - k2, (int)qw, true, fb->bulk, gb);
+                    if (rec) (void)hipEventRecord(rec, fb->bulk);
+                    if (rcf) return rcf;
+                    far_launched = true;
+                }
+                const int64_t far_tiles = far_on_bulk ? 0 : tf * (tf + 1) / 2;
                 // How many of these K = 256 tiles each launch takes.  A launch's riders run in ROUNDS of
                 // (2 workgroups per compute unit - the launch's own chain workgroups), ~20 us per round of
                 // K = 256 tiles, and a launch lasts max(its chain part, its rounds): whole rounds are given
                 // to the launches whose chain part they lengthen least (a launch with 1.3 rounds of riders
                 // takes two rounds' time: the first version of this schedule, split by the chain parts'
                 // durations, took 221 us per panel at 4352 trailing rows where 7 packed rounds take ~150).
-                const int slots = 2 * 256;
+                const int slots = 2 * (far_on_bulk ? 256 - fb->cus : 256);
                 const double t_round = 20.0;
                 const int64_t rows_below = n - k1;
                 int nchain_i[5], fixed_i[5];
@@ -1731,13 +1767,36 @@ static int fused_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, T* 
                 add(2 + sblk, rect_job(kmat + k1 * ld + k1, ld, kmat + k1 * ld + cs, ld, kmat + k1 * ld + cs, ld, n - k1, wn, SB));
             }
         }
+        if (fb) {
+            // the FAR launched during the previous iteration wrote the columns this chain's riders (and, when FAR
+            // rides again, its FAR tiles) are about to touch
+            if (ev_far_last) {
+                hipError_t e = hipStreamWaitEvent(st, ev_far_last, 0);
+                if (e != hipSuccess) return check_hip(e, fn, "hipStreamWaitEvent");
+                ev_far_last = nullptr;
+            }
+            if (far_launched) {
+                ev_far_last = next_event();
+                hipError_t e = hipEventRecord(ev_far_last, fb->bulk);
+                if (e != hipSuccess) return check_hip(e, fn, "hipEventRecord");
+            }
+        }
         int rc = panel_chain<T>(kmat, n, ld, ws, info, k0, w, b, m, ldb, bt, st, fn, true, false, rd, ph3_pending);
         if (rc) return rc;
+        if (fb && k1 < n) {
+            ev_prev_final = next_event();
+            hipError_t e = hipEventRecord(ev_prev_final, st);
+            if (e != hipSuccess) return check_hip(e, fn, "hipEventRecord");
+        }
         q0 = k0;
         qw = w;
         ph3_pending = (wn > 0 && w == CIMRGP_NB);
         rows_pending = rows && k1 < n;
         // a ragged panel that still has columns to its right cannot happen (only the last panel is ragged)
+    }
+    if (fb && ev_far_last) {
+        hipError_t e = hipStreamWaitEvent(st, ev_far_last, 0);
+        if (e != hipSuccess) return check_hip(e, fn, "hipStreamWaitEvent");
     }
     return 0;
 }
@@ -2068,7 +2127,15 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
                 rc = gemm_nt_sub<T>(k + k1 * ld + k1, ld, k + k1 * ld + k0, ld, k + k1 * ld + k0, ld,
                                     n - k1, kn - k1, (int)w, false, st);
                 if (rc) return rc;
-                rc = fused_sweep<T>(k, n, ld, ws, info, rows ? b : (T*)nullptr, rows ? m : 0, rows ? ldb : 0, PotrfBatch(), st, k1, w);
+                FarBulk fbk;
+                fbk.bulk = sp;                              // the chain's queue of the look-ahead phase is free now
+                fbk.ev = &la->ev;
+                fbk.ne = &ne;
+                fbk.cus = knobs().tail_far_cus;
+                fbk.min_rows = knobs().tail_far_min_rows;
+                const bool use_fb = !rows && fbk.cus >= 8 && knobs().gemm_pers >= 8;
+                rc = fused_sweep<T>(k, n, ld, ws, info, rows ? b : (T*)nullptr, rows ? m : 0, rows ? ldb : 0, PotrfBatch(), st, k1, w,
+                                    use_fb ? &fbk : nullptr);
                 if (rc) return rc;
             }
             tail_done = true;
