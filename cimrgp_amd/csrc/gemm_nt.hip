@@ -152,6 +152,26 @@ static __device__ __forceinline__ int pers_tile_number(int w, int i, int grid, i
 // flight.  (With the events inside a switch over the stage number hipcc waited for vmcnt(0) at the top
 // of every stage, and every stage then took a full HBM round trip under load: 40 against 45 TF/s for
 // the tile-per-workgroup kernel.)
+// Timing-only builds (tools/exp_variants.sh; 1-6 give WRONG results, never the shipped library):
+// -DPERS_EXP=1 no second barrier, 2 no barriers at all, 3 no C events, 4 C loads only, 5 C stores only,
+// 6 C loads always from the tile's first rows (L2 hits), 7 / 8 the C event issued in the middle / at the
+// end of the stage instead of its head (correct results).  Measured at M=7936, K=256:
+// 332 us shipped, 327 / 320 without barriers, 287-300 without the C events, 316 / 322 with only the loads /
+// stores, 327 with L2-hit loads, 332-335 for 7 and 8: the cost of streaming C is the memory pipeline's
+// share of the issue slots, not where in the stage the accesses sit and not the barriers.
+#ifndef PERS_EXP
+#define PERS_EXP 0
+#endif
+#if PERS_EXP == 1
+#define PERS_BARRIER_A() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define PERS_BARRIER_B() do { } while (0)
+#elif PERS_EXP == 2
+#define PERS_BARRIER_A() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define PERS_BARRIER_B() do { } while (0)
+#else
+#define PERS_BARRIER_A() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define PERS_BARRIER_B() asm volatile("s_barrier" ::: "memory")
+#endif
 constexpr int PERS_THREADS = 512;
 constexpr int PERS_STAGES = 16;
 
@@ -292,6 +312,26 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
     // One tile: `cur` holds its C (requested during the previous pass), `oth` the finished previous
     // tile, which is stored and replaced by the next tile's C as the K loop proceeds.  The ring position
     // of a stage is its number's parity (16 stages per tile).
+#define PERS_EVENT_BLOCK(oth_)                                                                             \
+        if (PERS_EXP != 3) {                    /* event kt */                                                  \
+                constexpr int EM = 0;  (void)EM;                                                                \
+                const int mi_ = kt >> 2, ne_ = (kt >> 1) & 1, r0_ = 2 * (kt & 1);                               \
+                if (kt >= 2) {                      /* the values requested two events ago have arrived */      \
+                    oth_[(kt - 2) >> 2][((kt - 2) >> 1) & 1][2 * ((kt - 2) & 1)] = tld[kt & 1][0];              \
+                    oth_[(kt - 2) >> 2][((kt - 2) >> 1) & 1][2 * ((kt - 2) & 1) + 1] = tld[kt & 1][1];          \
+                }                                                                                               \
+                const int64_t uo_ = (int64_t)(mi_ * 16 + RS * r0_) * ldc + ne_ * 16;                            \
+                T* sb_ = c_prv + uo_;                                                                           \
+                if (PERS_EXP != 4) {                                                                            \
+                    sb_[coff] = oth_[mi_][ne_][r0_];                                                            \
+                    (sb_ + (int64_t)RS * ldc)[coff] = oth_[mi_][ne_][r0_ + 1];                                  \
+                }                                                                                               \
+                const T* lb_ = (PERS_EXP == 6) ? c_nxt : c_nxt + uo_;                                           \
+                if (PERS_EXP != 5) {                                                                            \
+                    tld[kt & 1][0] = lb_[coff];                                                                 \
+                    tld[kt & 1][1] = (lb_ + (int64_t)RS * ldc)[coff];                                           \
+                }                                                                                               \
+            }
 #define PERS_PASS(cur_, oth_)                                                                                   \
     {                                                                                                           \
         const int tn_ = pers_tile_number(wg, it + 1, grid, ntiles);                                             \
@@ -305,34 +345,22 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
             PERS_SWRITE((kt & 1) ^ 1);              /* stage kt+1, in registers since the previous stage */     \
             if (kt + 2 < NKT) PERS_GLOAD(a_cur, b_cur, kt + 2)      /* stage kt+2 -> registers */                \
             else              PERS_GLOAD(a_nxt, b_nxt, kt + 2 - NKT)                                            \
-            {                                       /* event kt */                                              \
-                constexpr int EM = 0;  (void)EM;                                                                \
-                const int mi_ = kt >> 2, ne_ = (kt >> 1) & 1, r0_ = 2 * (kt & 1);                               \
-                if (kt >= 2) {                      /* the values requested two events ago have arrived */      \
-                    oth_[(kt - 2) >> 2][((kt - 2) >> 1) & 1][2 * ((kt - 2) & 1)] = tld[kt & 1][0];              \
-                    oth_[(kt - 2) >> 2][((kt - 2) >> 1) & 1][2 * ((kt - 2) & 1) + 1] = tld[kt & 1][1];          \
-                }                                                                                               \
-                const int64_t uo_ = (int64_t)(mi_ * 16 + RS * r0_) * ldc + ne_ * 16;                            \
-                T* sb_ = c_prv + uo_;                                                                           \
-                sb_[coff] = oth_[mi_][ne_][r0_];                                                                \
-                (sb_ + (int64_t)RS * ldc)[coff] = oth_[mi_][ne_][r0_ + 1];                                      \
-                const T* lb_ = c_nxt + uo_;                                                                     \
-                tld[kt & 1][0] = lb_[coff];                                                                     \
-                tld[kt & 1][1] = (lb_ + (int64_t)RS * ldc)[coff];                                               \
-            }                                                                                                   \
+            if (PERS_EXP != 7 && PERS_EXP != 8) PERS_EVENT_BLOCK(oth_)                                          \
             /* k-step s+1's fragments are requested before k-step s is multiplied (the scheduler is fenced */  \
             /* so that it cannot fold the pairs back into read -> wait -> multiply)                        */  \
             PERS_FRAGS_NF(1, kt & 1, 1);                                                                        \
             PERS_MMA_NF(cur_, 0);                                                                               \
             PERS_INTERLEAVE();                                                                                  \
             PERS_FRAGS(0, kt & 1, 2);                                                                           \
-            PERS_MMA(cur_, 1);                                                                                  \
+            if (PERS_EXP == 7) { PERS_EVENT_BLOCK(oth_) PERS_MMA_NF(cur_, 1); PERS_INTERLEAVE(); }                  \
+            else PERS_MMA(cur_, 1);                                                                             \
             PERS_FRAGS(1, kt & 1, 3);                                                                           \
             PERS_MMA(cur_, 0);                                                                                  \
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      /* stage kt+1 is in LDS */     \
+            PERS_BARRIER_A();                                                    /* stage kt+1 is in LDS */     \
             PERS_FRAGS(0, (kt & 1) ^ 1, 0);         /* first fragments of stage kt+1 */                         \
-            PERS_MMA(cur_, 1);                                                                                  \
-            asm volatile("s_barrier" ::: "memory");  /* everyone has read stage kt: its buffer may be rewritten */ \
+            if (PERS_EXP == 8) { PERS_EVENT_BLOCK(oth_) PERS_MMA_NF(cur_, 1); PERS_INTERLEAVE(); }                  \
+            else PERS_MMA(cur_, 1);                                                                             \
+            PERS_BARRIER_B();                        /* everyone has read stage kt: its buffer may be rewritten */ \
         }                                                                                                       \
         /* the last two events of the pass: the next tile's C is complete in `oth` */                          \
         oth_[3][1][0] = tld[0][0]; oth_[3][1][1] = tld[0][1];                                                   \
@@ -358,6 +386,7 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
         PERS_PASS(acc1, acc0)
     }
 #undef PERS_PASS
+#undef PERS_EVENT_BLOCK
 #undef PERS_INTERLEAVE
 #undef PERS_MMA
 #undef PERS_MMA_NF
