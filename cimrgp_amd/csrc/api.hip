@@ -44,6 +44,7 @@ const Knobs& knobs()
         v.rows_fused_tail = (int)num("CIMRGP_ROWS_FUSED", v.rows_fused_tail);
         v.rows_pair_above = num("CIMRGP_ROWS_PAIR", v.rows_pair_above);
         v.fused_max_chain_wgs = num("CIMRGP_FUSED_MAX", v.fused_max_chain_wgs);
+        v.batch_halves_min = (int)num("CIMRGP_BATCH_HALVES", v.batch_halves_min);
         v.rows_cus = (int)num("CIMRGP_ROWS_CUS", v.rows_cus);
         v.tail_far_cus = (int)num("CIMRGP_TAIL_FAR_CUS", v.tail_far_cus);
         v.tail_far_min_rows = num("CIMRGP_TAIL_FAR_MIN", v.tail_far_min_rows);

@@ -2322,6 +2322,30 @@ int potrf_batched_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, i
     // A big batch fills the machine with its panel solves already: the updates then keep launches of their own
     // (128-tiles, more efficient than 64-tile riders); riders pay where the chain's launches leave units idle.
     const bool ride = (int64_t)bt.count * (n / TR) <= knobs().fused_max_chain_wgs;
+    if (!ride && bt.count >= knobs().batch_halves_min && n > CIMRGP_NB) {
+        // Two halves of the batch on two queues: nothing orders them against each other, so the latency-bound
+        // panel chains of one half run beside the MFMA-bound updates of the other (one queue alternates
+        // between the two kinds of work and leaves the matrix cores idle for a third of a 128 x 2048 layer).
+        LookAhead* la = acquire_ctx(st);
+        if (la != nullptr) {
+            std::lock_guard<std::mutex> guard(la->enqueue);
+            if (!grow_events(la, 2)) return fail("cimrgp_potrf_batched", "hipEventCreate failed");
+            PotrfBatch h0 = bt, h1 = bt;
+            h0.count = bt.count / 2;
+            h1.count = bt.count - h0.count;
+            const int64_t c = h0.count;
+            CIMRGP_HIP_TRY(hipEventRecord(la->ev[0], st), "hipEventRecord");
+            CIMRGP_HIP_TRY(hipStreamWaitEvent(la->side, la->ev[0], 0), "hipStreamWaitEvent");
+            int rc = panel_sweep<T, true>(k, n, ld, ws, info, b, m, ldb, st, h0);
+            if (!rc) rc = build_invT<T>(k, n, ld, ws, st, h0);
+            if (!rc) rc = panel_sweep<T, true>(k + c * bt.sk, n, ld, ws + c * bt.sws, info + c, b ? b + c * bt.sb : b, m, ldb, la->side, h1);
+            if (!rc) rc = build_invT<T>(k + c * bt.sk, n, ld, ws + c * bt.sws, la->side, h1);
+            // (joined even after a failed enqueue: the caller's stream must not run ahead of the side queue)
+            CIMRGP_HIP_TRY(hipEventRecord(la->ev[1], la->side), "hipEventRecord");
+            CIMRGP_HIP_TRY(hipStreamWaitEvent(st, la->ev[1], 0), "hipStreamWaitEvent");
+            return rc;
+        }
+    }
     int rc = ride ? fused_sweep<T>(k, n, ld, ws, info, b, m, ldb, bt, st) : panel_sweep<T, true>(k, n, ld, ws, info, b, m, ldb, st, bt);
     return rc ? rc : build_invT<T>(k, n, ld, ws, st, bt);
 }
