@@ -11,6 +11,7 @@
 // The inverted 64x64 diagonal blocks stay in the workspace (slab c0/64) and
 // are what cimrgp_potrs / cimrgp_trsm_rows use afterwards.
 #include "common.hpp"
+#include <functional>
 #include "gemm_tile.hpp"
 #include <cstdlib>
 #include <mutex>
@@ -1342,36 +1343,42 @@ void k_trsm256(T* __restrict__ P, int64_t ldp, int M, int w, const T* __restrict
 
 // ---------------------------------------------------------------------------
 // 256x256 inverses of the diagonal blocks, for the skinny solves: the identity is
-// carried through the panel solve, batched over ALL panels (blockIdx.y), one launch
-// per 64-column sub-step:  invT_p = I L_pp^-T = (L_pp^-1)^T  (upper triangular,
-// row r = column r of L_pp^-1), stored 256 x 256 row-major per panel.
+// carried through the panel solve, batched over ALL panels (blockIdx.y):
+// invT_p = I L_pp^-T = (L_pp^-1)^T  (upper triangular, row r = column r of L_pp^-1),
+// stored 256 x 256 row-major per panel.  (Rounds 1-2: an init pass and one launch per
+// 64-column sub-step.)
 // ---------------------------------------------------------------------------
-template <typename T>
-__global__ void k_invT_init(T* __restrict__ invT, int n, int64_t sws = 0)
-{
-    invT += (int64_t)blockIdx.z * sws;
-    const int p = blockIdx.y;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;          // element of the 256 x 256 block
-    const int r = e >> 8, c = e & 255;
-    const int w = min(CIMRGP_NB, n - p * CIMRGP_NB);
-    invT[(int64_t)p * (CIMRGP_NB * CIMRGP_NB) + e] = (r == c && r < w) ? (T)1 : (T)0;
-}
-
+// ONE launch (round 3): a 32-row strip of the 256 x 256 block depends on no other strip, so its
+// workgroup runs the four 64-column sub-steps itself (its own earlier columns are read back from global memory
+// behind a workgroup barrier), writes the identity it starts from instead of a separate init pass, and skips
+// what is known to be zero: strip i has nothing left of column 32 i.  (Five dependent launches at the end of
+// every factorisation were 53 us of a N = 8192 step; 0.94 ms of a 128 x 2048 layer.)
 template <typename T>
 __global__ __launch_bounds__(256)
-void k_invT_step(T* __restrict__ invT, const T* __restrict__ L, int64_t ld, int n, const T* __restrict__ inv64, int s,
-                 int64_t sk = 0, int64_t sws = 0)
+void k_invT_panel(T* __restrict__ invT, const T* __restrict__ L, int64_t ld, int n, const T* __restrict__ inv64,
+                  int64_t sk = 0, int64_t sws = 0)
 {
     invT += (int64_t)blockIdx.z * sws;
     L += (int64_t)blockIdx.z * sk;
     inv64 += (int64_t)blockIdx.z * sws;
-    const int p = blockIdx.y;
-    const int k0 = p * CIMRGP_NB, c0 = k0 + SB * s;
-    const int kw = min(SB, n - c0);
-    if (kw <= 0) return;
-    T* Prow = invT + (int64_t)p * (CIMRGP_NB * CIMRGP_NB) + (int64_t)blockIdx.x * TR * CIMRGP_NB + SB * s;
+    const int p = blockIdx.y, strip = blockIdx.x;
+    const int k0 = p * CIMRGP_NB;
+    const int w = min(CIMRGP_NB, n - k0);
+    T* blk = invT + (int64_t)p * (CIMRGP_NB * CIMRGP_NB) + (int64_t)strip * TR * CIMRGP_NB;
+    for (int e = threadIdx.x; e < TR * CIMRGP_NB; e += 256) {
+        const int r = strip * TR + (e >> 8), c = e & 255;
+        blk[e] = (r == c && r < w) ? (T)1 : (T)0;
+    }
     __shared__ __attribute__((aligned(16))) unsigned char smem[TrsmLds<T>::BYTES];
-    trsm64_body<T>(smem, Prow, CIMRGP_NB, TR, kw, SB * s, L + (int64_t)c0 * ld + k0, ld, inv64 + (int64_t)(c0 / SB) * (SB * SB));
+    const int first = (strip * TR) / SB;                 // first 64-column block with a non-zero in this strip
+    for (int s = first; s < CIMRGP_NB / SB; ++s) {
+        const int c0 = k0 + SB * s;
+        const int kw = min(SB, n - c0);
+        if (kw <= 0) break;
+        __syncthreads();                                  // the strip's earlier columns (and the identity) are stored; LDS is free
+        trsm64_body<T>(smem, blk + SB * s, CIMRGP_NB, TR, kw, SB * (s - first), L + (int64_t)c0 * ld + k0 + SB * first, ld,
+                       inv64 + (int64_t)(c0 / SB) * (SB * SB));
+    }
 }
 
 // The panel chain's wait for the head tiles of a combined (head-first) persistent update: ONE workgroup polls the
@@ -1605,6 +1612,9 @@ struct FarBulk {
     size_t* ne = nullptr;
     int cus = 0;
     int64_t min_rows = 1 << 30;          // FAR on the bulk queue while n - k2 >= min_rows
+    // called once per panel [k0, k1) after its chain has been enqueued, with an event that says "panel final"
+    // (carried rows that follow the factorisation on queues of their own)
+    std::function<int(int64_t, int64_t, hipEvent_t)> on_final;
 };
 
 template <typename T>
@@ -1672,7 +1682,7 @@ static int fused_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, T* 
                 const int64_t near_tiles = tiles64(n - k1) * tiles64(wn);
                 const int64_t tf = (n > k2) ? tiles64(n - k2) : 0;
                 // FAR(prev) on the bulk queue (persistent, fb->cus units) while it is large; as riders otherwise
-                const bool far_on_bulk = fb && ev_prev_final && bt.count == 1 && n - k2 >= fb->min_rows && (n - k2) % 128 == 0 &&
+                const bool far_on_bulk = fb && fb->cus >= 8 && ev_prev_final && bt.count == 1 && n - k2 >= fb->min_rows && (n - k2) % 128 == 0 &&
                                          qw == CIMRGP_NB && gemm_pers_head_tiles(n - k2, (int)qw, (int)sizeof(T)) > 0;
                 if (far_on_bulk) {
                     hipError_t e = hipStreamWaitEvent(fb->bulk, ev_prev_final, 0);
@@ -1783,10 +1793,14 @@ static int fused_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, T* 
         }
         int rc = panel_chain<T>(kmat, n, ld, ws, info, k0, w, b, m, ldb, bt, st, fn, true, false, rd, ph3_pending);
         if (rc) return rc;
-        if (fb && k1 < n) {
+        if (fb && (k1 < n || fb->on_final)) {
             ev_prev_final = next_event();
             hipError_t e = hipEventRecord(ev_prev_final, st);
             if (e != hipSuccess) return check_hip(e, fn, "hipEventRecord");
+            if (fb->on_final) {
+                rc = fb->on_final(k0, k1, ev_prev_final);
+                if (rc) return rc;
+            }
         }
         q0 = k0;
         qw = w;
@@ -1942,14 +1956,9 @@ static int build_invT(const T* kmat, int64_t n, int64_t ld, T* ws, hipStream_t s
     const int64_t nslab = (n + SB - 1) / SB, npan = (n + CIMRGP_NB - 1) / CIMRGP_NB;
     T* invT = ws + nslab * (SB * SB);
     const unsigned nbatch = (unsigned)bt.count;
-    hipLaunchKernelGGL((k_invT_init<T>), dim3(CIMRGP_NB * CIMRGP_NB / 256, (unsigned)npan, nbatch), dim3(256), 0, st,
-                       invT, (int)n, bt.sws);
+    hipLaunchKernelGGL((k_invT_panel<T>), dim3(CIMRGP_NB / TR, (unsigned)npan, nbatch), dim3(256), 0, st,
+                       invT, kmat, ld, (int)n, (const T*)ws, bt.sk, bt.sws);
     CIMRGP_LAUNCH_CHECK(fn);
-    for (int s = 0; s < CIMRGP_NB / SB; ++s) {
-        hipLaunchKernelGGL((k_invT_step<T>), dim3(CIMRGP_NB / TR, (unsigned)npan, nbatch), dim3(256), 0, st,
-                           invT, kmat, ld, (int)n, (const T*)ws, s, bt.sk, bt.sws);
-        CIMRGP_LAUNCH_CHECK(fn);
-    }
     return 0;
 }
 
@@ -2097,7 +2106,14 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     for (int64_t k0 = 0; k0 < n; k0 += CIMRGP_NB) {
         const int64_t w  = (n - k0 < CIMRGP_NB) ? (n - k0) : CIMRGP_NB;
         const int64_t k1 = k0 + w;
-        if ((!rows || rows_fused) && k1 < n && n - k1 <= single_tail_below && !grp_open()) {
+        // With carried rows (round 3): the last rows_beside_tail_below columns are factored by the same one-queue fused
+        // sweep while the rows keep following on their own queues, one panel behind (the sweep tells them when a
+        // panel is final).  Entered later than the tail without rows (2560 against 4864 trailing columns): while the
+        // rows' far updates are large the sweep's riders would queue behind them for compute units (113 posteriors/s
+        // entered at 4864 and 107 at 6144 against 117.3 without and 119.4 at 2560).
+        const bool rows_beside = rows && !rows_fused && knobs().rows_beside_tail_below > 0;
+        if (k1 < n && !grp_open() && (rows_beside ? n - k1 <= knobs().rows_beside_tail_below
+                                                  : ((!rows || rows_fused) && n - k1 <= single_tail_below))) {
             // ---- single-stream tail.  Once the trailing matrix is small the look-ahead no longer
             // pays: its chain kernels wait for slots beside the update and every panel costs an
             // inter-queue hop, while one queue runs 4 x (diag + solve) = 124 us plus ONE update of
@@ -2114,7 +2130,11 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
             // (fused_sweep).  Carried rows first catch up with every panel up to k0 on their own queues
             // (the factorisation would be starved of compute units by their large updates anyway: it stood
             // still for ~2 ms of the round-2 schedule), then ride along.
-            if (rows) {
+            if (rows_beside) {
+                // the carried rows keep following on their own queues (panel k0 here, the tail's panels from the sweep)
+                rc = rows_after_panel(k0, k1, ev_panel);
+                if (rc) return rc;
+            } else if (rows) {
                 rc = rows_after_panel(k0, k1, ev_panel, true);
                 if (rc) return rc;
                 if (ev_rows_far) { CIMRGP_HIP_TRY(hipStreamWaitEvent(la->rows, ev_rows_far, 0), "hipStreamWaitEvent"); ev_rows_far = nullptr; }
@@ -2133,9 +2153,14 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
                 fbk.ne = &ne;
                 fbk.cus = knobs().tail_far_cus;
                 fbk.min_rows = knobs().tail_far_min_rows;
-                const bool use_fb = !rows && fbk.cus >= 8 && knobs().gemm_pers >= 8;
-                rc = fused_sweep<T>(k, n, ld, ws, info, rows ? b : (T*)nullptr, rows ? m : 0, rows ? ldb : 0, PotrfBatch(), st, k1, w,
-                                    use_fb ? &fbk : nullptr);
+                if (rows_beside) {
+                    fbk.cus = 0;                            // far updates as riders: the rows' far updates hold the persistent units
+                    fbk.on_final = [&](int64_t f0, int64_t f1, hipEvent_t evf) { return rows_after_panel(f0, f1, evf); };
+                }
+                const bool use_fb = rows_beside || (!rows && fbk.cus >= 8 && knobs().gemm_pers >= 8);
+                const bool ride_rows = rows && !rows_beside;
+                rc = fused_sweep<T>(k, n, ld, ws, info, ride_rows ? b : (T*)nullptr, ride_rows ? m : 0, ride_rows ? ldb : 0, PotrfBatch(), st,
+                                    k1, w, use_fb ? &fbk : nullptr);
                 if (rc) return rc;
             }
             tail_done = true;
