@@ -2183,26 +2183,11 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
                            group_size(n - k2 - ((n - k2 < CIMRGP_NB) ? (n - k2) : CIMRGP_NB), knobs().far_pair_above) == 1)
                               ? gemm_pers_head_tiles(n - k1, (int)w, (int)sizeof(T)) : 0;
         if (heads > 0) {
-            if (ev_rest) CIMRGP_HIP_TRY(hipStreamWaitEvent(sp, ev_rest, 0), "hipStreamWaitEvent");
-            // chain queue: first diagonal block (+ the rest of tile (0, 0) of 128 as riders), gate, the other links
-            Riders<T> r0 = no_riders<T>();
-            {
-                RiderJob<T>& jb = r0.job[0];
-                jb.c = k + k1 * ld + k1; jb.a = k + k1 * ld + k0; jb.b = k + k1 * ld + k0; jb.ldc = jb.lda = jb.ldb = ld;
-                jb.m = 128; jb.n = 128; jb.k = (int)w; jb.lower = 0; jb.tiles_n = 2; jb.first = 0; jb.count = 4; jb.skip00 = 1; jb.rows_job = 0;
-                r0.njobs = 1; r0.total = 4;
-            }
-            hipLaunchKernelGGL((k_diag64q<T>), dim3(1 + r0.total), dim3(Q_NT), 0, sp, k + k1 * ld + k1, ld, (int)SB,
-                               (const T*)(k + k1 * ld + k0), (int)w, ws + (k1 / SB) * (SB * SB), info, (int)k1, (int64_t)0, (int64_t)0,
-                               (int64_t)0, r0);
-            CIMRGP_LAUNCH_CHECK("cimrgp_potrf");
+            // The persistent launch is ENQUEUED before the gate that waits for its head tiles: a tool that runs one
+            // kernel at a time in submission order (rocprofv3 --pmc, HIP_LAUNCH_BLOCKING) then finds the count complete
+            // when the gate runs, instead of running the gate first and timing it out.
+            hipEvent_t ev_rest_prev = ev_rest;
             flag_expected += heads;
-            hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, sp, (const int*)la->flag, flag_expected, info);
-            CIMRGP_LAUNCH_CHECK("cimrgp_potrf");
-            rc = factor_panel<T>(k, n, ld, ws, info, k1, wn, sp, false, true);
-            if (rc) return rc;
-            hipEvent_t ev_next = la->ev[ne++];
-            CIMRGP_HIP_TRY(hipEventRecord(ev_next, sp), "hipEventRecord");
             // bulk queue: everything right of panel k0, the next panel's columns first
             CIMRGP_HIP_TRY(hipStreamWaitEvent(sb, ev_final, 0), "hipStreamWaitEvent");
             const double mm = (double)(n - k1);
@@ -2216,6 +2201,25 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
             ev_rest = la->ev[ne++];
             CIMRGP_HIP_TRY(hipEventRecord(ev_rest, sb), "hipEventRecord");
             ev_bulk_last = ev_rest;
+            // chain queue: first diagonal block (+ the rest of tile (0, 0) of 128 as riders), gate, the other links
+            if (ev_rest_prev) CIMRGP_HIP_TRY(hipStreamWaitEvent(sp, ev_rest_prev, 0), "hipStreamWaitEvent");
+            Riders<T> r0 = no_riders<T>();
+            {
+                RiderJob<T>& jb = r0.job[0];
+                jb.c = k + k1 * ld + k1; jb.a = k + k1 * ld + k0; jb.b = k + k1 * ld + k0; jb.ldc = jb.lda = jb.ldb = ld;
+                jb.m = 128; jb.n = 128; jb.k = (int)w; jb.lower = 0; jb.tiles_n = 2; jb.first = 0; jb.count = 4; jb.skip00 = 1; jb.rows_job = 0;
+                r0.njobs = 1; r0.total = 4;
+            }
+            hipLaunchKernelGGL((k_diag64q<T>), dim3(1 + r0.total), dim3(Q_NT), 0, sp, k + k1 * ld + k1, ld, (int)SB,
+                               (const T*)(k + k1 * ld + k0), (int)w, ws + (k1 / SB) * (SB * SB), info, (int)k1, (int64_t)0, (int64_t)0,
+                               (int64_t)0, r0);
+            CIMRGP_LAUNCH_CHECK("cimrgp_potrf");
+            hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, sp, (const int*)la->flag, flag_expected, info);
+            CIMRGP_LAUNCH_CHECK("cimrgp_potrf");
+            rc = factor_panel<T>(k, n, ld, ws, info, k1, wn, sp, false, true);
+            if (rc) return rc;
+            hipEvent_t ev_next = la->ev[ne++];
+            CIMRGP_HIP_TRY(hipEventRecord(ev_next, sp), "hipEventRecord");
             ev_panel = ev_next;
             rc = rows_after_panel(k0, k1, ev_final);
             if (rc) return rc;
