@@ -1,10 +1,10 @@
 #!/bin/bash
 # Collect the judged profiles of the N = 8192 bench on the GPU box (run from the repo root):
-#   bash tools/collect_profiles.sh r03 [part ...]     parts: bench stats timelines pmc sweep configs rccl (default: all)
+#   bash tools/collect_profiles.sh r03 [part ...]     parts: bench stats timelines pmc sweep configs rccl variants (default: all)
 # -> gpurun_out/r03_*; then locally:  python3 tools/finalize_profiles.py r03   (copies what is kept into profiles/,
 # stamps the commit).  rocprofv3: counters in their own passes with --kernel-trace only; the program itself after `--`.
 tag=${1:-rXX}; shift || true
-parts=${*:-"bench stats timelines pmc sweep configs rccl"}
+parts=${*:-"bench stats timelines pmc sweep configs rccl variants"}
 out=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 want() { case " $parts " in *" $1 "*) return 0;; esac; return 1; }
@@ -41,6 +41,11 @@ if want sweep; then
     python3 tools/potrf_sweep.py --sizes 2048,4096,8192,16384 --rows >> $out/${tag}_potrf_sweep.jsonl 2>/dev/null
     python3 tools/potrf_sweep.py --sizes 8192,16384 --dtype f32 >> $out/${tag}_potrf_sweep.jsonl 2>/dev/null
     python3 tools/gemm_bench.py --m 7936,6912,5888,4864 --k 256 --reps 20 --check > $out/${tag}_gemm_standalone.jsonl 2>/dev/null
+    # the tile-per-workgroup kernel on the same sizes (tuning build: the persistent form switched off)
+    CIMRGP_LIB_PATH=$PWD/cimrgp_amd/libcimrgp_tuning.so CIMRGP_GEMM_PERS=0 python3 tools/gemm_bench.py --m 7936,6912,5888,4864 --k 256 --reps 20 --check \
+        > $out/${tag}_gemm_standalone_tile_kernel.jsonl 2>/dev/null
+    # one layer's batched fit + prediction, stand-alone
+    { python3 tools/layer_time.py 128 2048 5 2>/dev/null | tail -1; python3 tools/layer_time.py 64 4096 3 2>/dev/null | tail -1; } > $out/${tag}_layer_times.jsonl
 fi
 if want configs; then
     python3 bench.py --config 3 --steps 3 --warmup 1 > $out/${tag}_config3_n65536.json 2> $out/${tag}_config3.err || tail -5 $out/${tag}_config3.err
@@ -51,5 +56,9 @@ if want rccl; then
     for mode in "" "--nccl-world1" "--nccl-world1 --rows-queues 1"; do
         python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline $mode 2>/dev/null | tail -1
     done > $out/${tag}_rccl_world_of_one.jsonl
+fi
+if want variants && [ -f cimrgp_amd/libcimrgp_tuning_e1.so ]; then
+    # timing-only builds of the persistent kernel (built beforehand: bash tools/exp_variants.sh build)
+    bash tools/exp_variants.sh > $out/${tag}_pers_variants.txt 2>&1
 fi
 echo collected
