@@ -422,7 +422,7 @@ static int gemm_launch(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, i
 int gemm_pers_head_tiles(int64_t m, int k, int elem_bytes)
 {
     const int bke = KT_BYTES / elem_bytes;
-    if (knobs().gemm_pers < 8 || m % 128 != 0 || m / 128 < 3 || k % bke != 0 || k / bke != PERS_STAGES) return 0;
+    if (elem_bytes != 8 || knobs().gemm_pers < 8 || m % 128 != 0 || m / 128 < 3 || k % bke != 0 || k / bke != PERS_STAGES) return 0;
     return (int)(2 * (m / 128) - 2);
 }
 
@@ -459,7 +459,9 @@ int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t 
         constexpr int bke = KT_BYTES / (int)sizeof(T);
         const int want = (bt.pers >= 0) ? bt.pers : knobs().gemm_pers;
         const int nkt = (k % bke) ? 0 : k / bke;
-        if (want >= 8 && nkt == PERS_STAGES && bt.count == 1 && !bt.skip_first && m % 128 == 0 && n % 128 == 0 &&
+        // (FP64 only: an FP32 pass is K = 512 -- paired panels -- and runs at twice the matrix rate over the same C
+        // traffic per tile; measured slower than the tile kernel, whole potrf at n = 16 384: 18.6 against 17.1 ms)
+        if (sizeof(T) == 8 && want >= 8 && nkt == PERS_STAGES && bt.count == 1 && !bt.skip_first && m % 128 == 0 && n % 128 == 0 &&
             ldc < (1ll << 23) && lda < (1ll << 23) && ldb < (1ll << 23) && (t128 >= knobs().pers_min_tiles || bt.head_first || bt.pers_force)) {
             const int64_t tm = m / 128, tn = n / 128;
             // head-first launch (the look-ahead's combined head + bulk update): tile (0, 0) is left to the chain
