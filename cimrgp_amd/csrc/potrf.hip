@@ -1852,7 +1852,7 @@ LookAhead* make_ctx(int dev)
     bool ok = hipStreamCreateWithPriority(&la->side, hipStreamNonBlocking, hi) == hipSuccess;
     // (Round 2 could run the update kernels on CU-masked queues -- hipExtStreamCreateWithCUMask,
     // CIMRGP_RESERVE_CUS -- to keep compute units free for the chain: measured useless three times
-    // (rejected (i)) and removed in round 3: masked streams are BLOCKING streams that
+    // (HISTORY.md, rounds 1-2, rejected (i)) and removed in round 3: masked streams are BLOCKING streams that
     // synchronise with the legacy default stream, and they were the one kind of object still alive at
     // process exit in the profiler runs that crashed in an exit handler.  The persistent update kernel
     // splits the machine instead: a launch of G workgroups occupies G compute units.)
