@@ -120,6 +120,9 @@ def launch_ranks(args):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # RCCL shares device buffers between the ranks of a node through IPC handles; the host driver of this
+        # pool only supports dmabuf IPC, and without this switch hipIpcGetMemHandle fails with "invalid argument"
+        # at communicator creation (the image exports it already: kept for environments built by hand)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("OMP_NUM_THREADS", "8")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))

@@ -202,6 +202,7 @@ class MultiResolutionGaussianProcess(object):
         n, q = self._y.shape
         f_bar = torch.zeros_like(self._y)
         self._layer_events = [torch.cuda.Event(enable_timing=True) for _ in range(self.n_layers + 1)]
+        failed = torch.zeros(self.n_layers, dtype=self.dtype, device=self.device)
         for j in range(self.n_layers):
             self._layer_events[j].record()
             self._f_bar_layers[j] = f_bar
@@ -219,11 +220,17 @@ class MultiResolutionGaussianProcess(object):
             # residual chain (Stats.py:126-157): every rank needs the whole layer's prediction
             dist.allreduce_sum_(buf, self.group)
             f_bar = f_bar + layer_pred
-            if float(buf[n * q].item()) != 0.0:
-                self.posterior_obj[j].check(owned)           # the owner reports the leading minor
-                raise np.linalg.LinAlgError('Matrix is not positive definite (a block of layer %d '
-                                            'owned by another rank)' % j)
+            failed[j:j + 1].copy_(buf[n * q:])               # read ONCE, after the sweep: the fit stays enqueue-only
         self._layer_events[self.n_layers].record()
+        # (a host read per layer made the device wait for the host's enqueue of the next layer: 2-3 ms on the
+        # fine layers of config 4.  After a failed factorisation the later layers run on garbage -- harmless:
+        # every kernel is bounded and flags its own `info` -- and the first failing layer is the one reported.)
+        flags = failed.cpu().numpy()
+        if np.any(flags != 0.0):
+            j = int(np.flatnonzero(flags != 0.0)[0])
+            self.posterior_obj[j].check(self._owned(j))      # the owner reports the leading minor
+            raise np.linalg.LinAlgError('Matrix is not positive definite (a block of layer %d '
+                                        'owned by another rank)' % j)
         self._f_bar_final = f_bar
         self._fitted = True
 
