@@ -358,14 +358,27 @@ def main():
             ev[3].record()
         z = wbuf[ns:ns + q, :n].t().contiguous()
         alpha = dev.solve_lt(kbuf, n, ws, z.clone())                                # D3 backward half
+        # the previous step's collective owns `fused` until it is done: the stream waits for it HERE, a whole
+        # factorisation after it was started, so its latency never shows (the host does not block)
+        if pending[0] is not None:
+            pending[0].wait()
+            pending[0] = None
+        fused.zero_()                                                               # the other ranks' slices
         var = fused[q, rank * ns:(rank + 1) * ns]
         dev.predict_from_w(wbuf, ns, n, z, sf2, 0.0, None, mean, var, accumulate=False)   # D4 + D5 tail
         if timed:
             ev[4].record()
         fused[:q, rank * ns:(rank + 1) * ns] = mean.t()
-        dist.allreduce_sum_(fused, force=args.nccl_world1)                          # the one collective
+        pending[0] = dist.allreduce_sum_begin(fused, force=args.nccl_world1)        # the one collective
         if timed:
             ev[5].record()
+
+    pending = [None]
+
+    def drain():
+        if pending[0] is not None:
+            pending[0].wait()
+            pending[0] = None
 
     def barrier():
         if world > 1:
@@ -374,6 +387,7 @@ def main():
 
     for _ in range(args.warmup):
         step(False)
+    drain()
     barrier()
     assert int(info.item()) == 0, "Cholesky failed in warm-up"
 
@@ -382,6 +396,7 @@ def main():
     for _ in range(args.steps):
         step(True)
         # stage times are read after the loop from the last step's events only
+    drain()                                       # the last step's collective completes inside the timed region
     barrier()
     dt = time.perf_counter() - t0
     tr_ms, tr_fl, tr_by, tr_cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
@@ -389,6 +404,8 @@ def main():
                "cimrgp_profile_collect_bytes")
     for i in range(5):
         stage_ms[i] = ev[i].elapsed_time(ev[i + 1])
+    # the reduced buffer holds this rank's slice unchanged (the other ranks contribute zeros there): exact
+    reduce_diff = float((fused[:q, rank * ns:(rank + 1) * ns] - mean.t()).abs().max().item())
     last_mean = mean.double().cpu().numpy()                    # the last timed step's outputs (this rank)
     last_var = fused[q, rank * ns:(rank + 1) * ns].double().cpu().numpy()
     # Cholesky alone (no carried rows) for the effective-GFLOP/s figure, timed separately
@@ -435,6 +452,7 @@ def main():
                        "partitions_per_gpu": 1, "parallelism": "independent partitions, 1 all-reduce/step",
                        "backend": (rehearsal or "nccl") if td.is_initialized() else "none",
                        "rows_queues": int(lib.cimrgp_get_rows_queues())},
+            "reduce_selfcheck_max_abs_diff": reduce_diff,
             "cholesky_gflops": chol_gflops,
             "cholesky_frac_of_peak": chol_gflops / 1e3 / peak,
             "stage_ms": {"gram": stage_ms[0], "cross_gram_and_rhs_rows": stage_ms[1],

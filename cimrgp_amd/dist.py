@@ -48,6 +48,16 @@ def allreduce_sum_(tensor, group=None, force=False):
     return tensor
 
 
+def allreduce_sum_begin(tensor, group=None, force=False):
+    """Start the in-place sum over ranks and return at once: the handle's ``wait()`` makes the CURRENT STREAM
+    wait for the collective (it does not block the host).  None when there is nothing to reduce.  A caller that
+    next touches ``tensor`` a whole step later (bench.py) waits there and hides the collective behind the step."""
+    _, ws = world(group)
+    if ws > 1 or (force and td.is_available() and td.is_initialized()):
+        return td.all_reduce(tensor, op=td.ReduceOp.SUM, group=group, async_op=True)
+    return None
+
+
 def share_one_gpu():
     """Several ranks SHARE one GPU (rehearsals and the 2-rank tests on a one-GPU box; production runs one
     process per GPU).  Each process must then stay within the runtime's four hardware queues: one queue for
