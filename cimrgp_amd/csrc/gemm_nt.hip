@@ -155,10 +155,11 @@ static __device__ __forceinline__ int pers_tile_number(int w, int i, int grid, i
 // Timing-only builds (tools/exp_variants.sh; 1-6 give WRONG results, never the shipped library):
 // -DPERS_EXP=1 no second barrier, 2 no barriers at all, 3 no C events, 4 C loads only, 5 C stores only,
 // 6 C loads always from the tile's first rows (L2 hits), 7 / 8 the C event issued in the middle / at the
-// end of the stage instead of its head (correct results).  Measured at M=7936, K=256:
-// 332 us shipped, 327 / 320 without barriers, 287-300 without the C events, 316 / 322 with only the loads /
-// stores, 327 with L2-hit loads, 332-335 for 7 and 8: the cost of streaming C is the memory pipeline's
-// share of the issue slots, not where in the stage the accesses sit and not the barriers.
+// end of the stage instead of its head (correct results).  Measured at M=7936, K=256 (DESIGN.md section 4,
+// round 3 (1); profiles/r03_pers_variants.txt): without the C events the pass is ~10 % shorter, with only the
+// loads or only the stores ~4 %, without the barriers 2-4 %, and moving the event within the stage changes
+// nothing: the cost of streaming C is the memory pipeline's share of the issue slots, not where in the stage
+// the accesses sit and not the barriers.
 #ifndef PERS_EXP
 #define PERS_EXP 0
 #endif
