@@ -94,6 +94,45 @@ def test_single_process_world_is_identity():
     assert dist.allreduce_sum_(t) is t
 
 
+def _async_reduce_worker(rank, world, port, out_dir):
+    """bench.py's pattern: every rank writes its slice of a zeroed fused buffer, the reduce is started and only
+    waited for when the buffer is touched again one step later."""
+    sys.path.insert(0, ROOT)
+    from cimrgp_amd import dist
+    td.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    ns = 5
+    fused = torch.zeros((3, ns * world), dtype=torch.float64)
+    pending = None
+    seen = []
+    for step in range(3):
+        if pending is not None:
+            pending.wait()
+            seen.append(fused.clone())
+        fused.zero_()
+        fused[:, rank * ns:(rank + 1) * ns] = float(10 * step + rank + 1)
+        pending = dist.allreduce_sum_begin(fused)
+        assert pending is not None
+    pending.wait()
+    seen.append(fused.clone())
+    np.save(os.path.join(out_dir, "async%d.npy" % rank), torch.stack(seen).numpy())
+    td.destroy_process_group()
+
+
+def test_async_reduce_of_the_fused_buffer_two_ranks(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_async_reduce_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = [np.load(os.path.join(str(tmp_path), "async%d.npy" % r)) for r in range(world)]
+    np.testing.assert_array_equal(got[0], got[1])
+    for step in range(3):
+        for r in range(world):
+            assert np.all(got[0][step][:, r * 5:(r + 1) * 5] == 10 * step + r + 1)   # no stale slices from earlier steps
+
+
+def test_async_reduce_is_a_no_op_for_one_process():
+    from cimrgp_amd import dist
+    assert dist.allreduce_sum_begin(torch.ones(3)) is None
+
+
 def _failing_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     from cimrgp_amd import dist
