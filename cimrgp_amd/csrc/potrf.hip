@@ -747,12 +747,98 @@ static __device__ __forceinline__ void trsm64_body(unsigned char* smem, T* __res
     STAMP(12);
 }
 
+// The same solve for G consecutive 32-row tiles in ONE workgroup (batched launches, round 3).  In a batch of
+// many blocks the panel solves are not latency- but L2-bandwidth-bound: every 32-row workgroup streams the
+// block's 64 x kprev strip of L and its 64 x 64 inverse (80-130 KB) for 16-48 KB of its own rows -- 600 MB per
+// launch for 128 blocks of 2048.  Here a chunk of L is staged once per G tiles and the inverse once per
+// workgroup; the tiles' operand strips follow one another through the same LDS area.
+constexpr int TRSM_GROUP = 4;
+template <typename T, int G>
+static __device__ __forceinline__ void trsm64_group(unsigned char* smem, T* __restrict__ Prow, int64_t ldp, int mrows, int kw, int kprev,
+                                                     const T* __restrict__ Lrow, int64_t ldl, const T* __restrict__ invL)
+{
+    using X = Mx<T>;
+    using TL = Tile64<T>;
+    using acc_t = typename X::acc_t;
+    unsigned char* ps = smem;                          // P_s of one tile, then T
+    unsigned char* as = smem + TR * TL::LROW;          // chunk of one tile's earlier panel columns
+    unsigned char* bs = smem + 2 * TR * TL::LROW;      // chunk of Lrow, finally invL
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rt = wave & 1, ch = wave >> 1;
+    __builtin_amdgcn_s_setprio(3);
+    const T* Pprev = Prow - kprev;
+    v4u ra[TR * TL::CPR / 256], rb[SB * TL::CPR / 256], rinv[SB * TL::CPR / 256];
+#pragma unroll
+    for (int p = 0; p < SB * TL::CPR / 256; ++p) {
+        const int e = tid + 256 * p, r = e / TL::CPR, c = e - r * TL::CPR;
+        rinv[p] = *reinterpret_cast<const v4u*>(invL + r * SB + c * X::EPC);
+    }
+    acc_t acc[G][2];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { acc[g][0] = acc_zero<T>(); acc[g][1] = acc_zero<T>(); }
+    if (kprev > 0) {
+        gload_tile64<T, SB>(rb, Lrow, ldl, kw, SB);
+        gload_tile64<T, TR>(ra, Pprev, ldp, mrows, SB);
+    }
+    for (int kc = 0; kc < kprev; kc += SB) {
+        __syncthreads();                               // the previous chunk's fragments have been read
+        swrite_tile64<T, SB>(bs, rb);
+        if (kc + SB < kprev) gload_tile64<T, SB>(rb, Lrow + kc + SB, ldl, kw, SB);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (g) __syncthreads();                    // the previous tile's fragments have been read
+            swrite_tile64<T, TR>(as, ra);
+            __syncthreads();
+            // next operand strip in flight during the multiplies: the next tile's, or tile 0's of the next chunk
+            if (g + 1 < G) gload_tile64<T, TR>(ra, Pprev + (int64_t)(g + 1) * TR * ldp + kc, ldp, mrows - (g + 1) * TR, SB);
+            else if (kc + SB < kprev) gload_tile64<T, TR>(ra, Pprev + kc + SB, ldp, mrows, SB);
+            mma_chunk32<T, false>(acc[g], as, bs, rt, ch, lane);
+        }
+    }
+    __syncthreads();
+    swrite_tile64<T, SB>(bs, rinv);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int rows_g = mrows - g * TR;             // workgroup-uniform
+        if (rows_g > 0) {
+            T* Pg = Prow + (int64_t)g * TR * ldp;
+            __syncthreads();                           // the previous tile's T has been read; invL is in place
+            load_tile64<T, TR>(ps, Pg, ldp, rows_g < TR ? rows_g : TR, kw);
+            __syncthreads();
+            if (kprev > 0) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = rt * 16 + X::crow(lane, r), col = (2 * ch + c) * 16 + (lane & 15);
+                        T* t = reinterpret_cast<T*>(ps + row * TL::LROW) + col;
+                        *t -= acc[g][c][r];
+                    }
+            }
+            __syncthreads();
+            acc_t x[2];
+            x[0] = acc_zero<T>(); x[1] = acc_zero<T>();
+            mma_chunk32<T, true>(x, ps, bs, rt, ch, lane);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int gc = (2 * ch + c) * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int lr = rt * 16 + X::crow(lane, r);
+                    if (lr < rows_g && gc < kw) Pg[(int64_t)lr * ldp + gc] = x[c][r];
+                }
+            }
+        }
+    }
+}
+
 template <typename T>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, 2)
 void k_trsm64(T* __restrict__ P1, int64_t ld1, int M1, int nb1,
               T* __restrict__ P2, int64_t ld2, int M2,
               int kw, int kprev, const T* __restrict__ Lrow, int64_t ldl, const T* __restrict__ invL,
-              int64_t sk, int64_t sws, int64_t sb, int nchain, Riders<T> rd)
+              int64_t sk, int64_t sws, int64_t sb, int nchain, Riders<T> rd, int trg)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[ChainLds<T>::BYTES];
     if ((int)blockIdx.x >= nchain) {                 // riders
@@ -767,8 +853,10 @@ void k_trsm64(T* __restrict__ P1, int64_t ld1, int M1, int nb1,
     T* P = second ? P2 : P1;
     const int64_t ldp = second ? ld2 : ld1;
     const int M = second ? M2 : M1;
-    const int row0 = (second ? (int)blockIdx.x - nb1 : (int)blockIdx.x) * TR;
-    trsm64_body<T>(smem, P + (int64_t)row0 * ldp, ldp, min(TR, M - row0), kw, kprev, Lrow, ldl, invL);
+    // trg = rows per workgroup: TR, or TR x TRSM_GROUP in batched launches (nb1 counts workgroups of that size)
+    const int row0 = (second ? (int)blockIdx.x - nb1 : (int)blockIdx.x) * trg;
+    if (trg == TR) trsm64_body<T>(smem, P + (int64_t)row0 * ldp, ldp, min(TR, M - row0), kw, kprev, Lrow, ldl, invL);
+    else           trsm64_group<T, TRSM_GROUP>(smem, P + (int64_t)row0 * ldp, ldp, min(trg, M - row0), kw, kprev, Lrow, ldl, invL);
 }
 
 // ---------------------------------------------------------------------------
@@ -1162,7 +1250,7 @@ template <typename T>
 __global__ __launch_bounds__(Q_NT, 2)
 void k_linkq(T* __restrict__ A, int64_t ld, int n, int c0, int k0, int wn,
              T* __restrict__ P2, int64_t ld2, int M2, T* __restrict__ ws, int32_t* info,
-             int64_t sk, int64_t sws, int64_t sb, int nchain, Riders<T> rd)
+             int64_t sk, int64_t sws, int64_t sb, int nchain, Riders<T> rd, int trg)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[ChainLds<T>::BYTES];
     if ((int)blockIdx.x >= nchain) {                 // riders
@@ -1181,15 +1269,17 @@ void k_linkq(T* __restrict__ A, int64_t ld, int n, int c0, int k0, int wn,
     const T* Lrow = A + (int64_t)c0 * ld + k0;
     const int r0 = c0 + SB;
     if (blockIdx.x != 0) {
+        // trg = rows per solve workgroup: TR, or TR x TRSM_GROUP in batched launches (k_trsm64)
         const int pc = r0 + wn;
-        const int M1 = n - pc, nb1 = (M1 + TR - 1) / TR;
+        const int M1 = n - pc, nb1 = (M1 + trg - 1) / trg;
         const int b = (int)blockIdx.x - 1;
         const bool second = b >= nb1;
         T* P = second ? P2 : A + (int64_t)pc * ld + c0;
         const int64_t ldp = second ? ld2 : ld;
         const int M = second ? M2 : M1;
-        const int row0 = (second ? b - nb1 : b) * TR;
-        trsm64_body<T>(smem, P + (int64_t)row0 * ldp, ldp, min(TR, M - row0), SB, kprev, Lrow, ld, invL);
+        const int row0 = (second ? b - nb1 : b) * trg;
+        if (trg == TR) trsm64_body<T>(smem, P + (int64_t)row0 * ldp, ldp, min(TR, M - row0), SB, kprev, Lrow, ld, invL);
+        else           trsm64_group<T, TRSM_GROUP>(smem, P + (int64_t)row0 * ldp, ldp, min(trg, M - row0), SB, kprev, Lrow, ld, invL);
         return;
     }
     constexpr int NR = SB * TL::CPR / Q_NT;
@@ -1454,7 +1544,9 @@ static int panel_chain(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, int
     const bool rows = (b != nullptr && m > 0);
     const unsigned nbatch = (unsigned)bt.count;
     const int64_t k1 = k0 + w;
-    const int nb2 = rows ? (int)((m + TR - 1) / TR) : 0;
+    // rows per panel-solve workgroup: groups of TRSM_GROUP tiles in batched launches (k_linkq / k_trsm64 take it as an argument)
+    const int trg = (bt.count > 1 && waves4 && knobs().trsm_group) ? TR * TRSM_GROUP : TR;
+    const int nb2 = rows ? (int)((m + trg - 1) / trg) : 0;
     const Riders<T> none = no_riders<T>();
     int launch = 0;                                   // 0: first diagonal block, 1..3: links, 4: last panel solve
     for (int64_t c0 = k0; c0 < k1; c0 += SB) {
@@ -1479,14 +1571,14 @@ static int panel_chain(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, int
         if (!split_links && pc < k1) {
             const int wn = (int)((k1 - pc < SB) ? (k1 - pc) : SB);         // next diagonal block of this panel
             const int64_t m1 = n - (pc + wn);
-            const int nb1 = (int)((m1 + TR - 1) / TR);
+            const int nb1 = (int)((m1 + (waves4 ? trg : TR) - 1) / (waves4 ? trg : TR));
             ++launch;
             const Riders<T>& rd = (riders && launch <= 3) ? riders[launch] : none;
             const int nchain = 1 + nb1 + nb2;
             if (waves4)
                 hipLaunchKernelGGL((k_linkq<T>), dim3((unsigned)(nchain + rd.total), nbatch), dim3(Q_NT), 0, st,
                                    kmat, ld, (int)n, (int)c0, (int)k0, wn, rows ? b + c0 : (T*)nullptr, ldb, rows ? (int)m : 0,
-                                   ws, info, bt.sk, bt.sws, bt.sb, nchain, rd);
+                                   ws, info, bt.sk, bt.sws, bt.sb, nchain, rd, trg);
             else
                 hipLaunchKernelGGL((k_link<T>), dim3((unsigned)(nchain + rd.total), nbatch), dim3(DG_NT), 0, st,
                                    kmat, ld, (int)n, (int)c0, (int)k0, wn, rows ? b + c0 : (T*)nullptr, ldb, rows ? (int)m : 0,
@@ -1495,13 +1587,13 @@ static int panel_chain(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, int
             continue;
         }
         const int64_t m1 = n - pc;
-        const int nb1 = (int)((m1 + TR - 1) / TR);
+        const int nb1 = (int)((m1 + trg - 1) / trg);
         const Riders<T>& rd = (riders && !split_links && pc == k1) ? riders[4] : none;
         if (nb1 + nb2 + rd.total > 0) {
             hipLaunchKernelGGL((k_trsm64<T>), dim3((unsigned)(nb1 + nb2 + rd.total), nbatch), dim3(256), 0, st,
                                kmat + pc * ld + c0, ld, (int)m1, nb1,
                                rows ? b + c0 : (T*)nullptr, ldb, rows ? (int)m : 0,
-                               sw, kprev, lrow, ld, (const T*)inv, bt.sk, bt.sws, bt.sb, nb1 + nb2, rd);
+                               sw, kprev, lrow, ld, (const T*)inv, bt.sk, bt.sws, bt.sb, nb1 + nb2, rd, trg);
             CIMRGP_LAUNCH_CHECK(fn);
         }
     }

@@ -8,7 +8,7 @@ import csv,glob
 f=sorted(glob.glob("gpurun_out/lay_stats/*/*kernel_stats.csv"))[-1]
 rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:-float(r["TotalDurationNs"]))
-for r in rows[:16]:
+for r in rows[:22]:
     print(r["Name"][:70].ljust(70), r["Calls"].rjust(5), "%9.1f us avg" % (float(r["AverageNs"])/1e3), "%6.1f %%" % float(r["Percentage"]))
 PY
 rm -rf gpurun_out/lay_stats
