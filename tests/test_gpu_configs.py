@@ -321,6 +321,16 @@ def test_bench_config4_two_ranks_prints_one_checked_line():
     assert rec["parity_ok"] is True and rec["parity_rel_err_mean"] < 1e-7 and rec["parity_rel_err_var_elementwise"] < 1e-5
 
 
+def test_bench_weak_scaling_two_ranks_reduce_is_exact():
+    """``bench.py --gpus 2`` (the driver's weak-scaling command; here two ranks share the card under gloo): one line,
+    two posteriors per step, and the asynchronously started reduce of the fused [mean | var] buffer returns rank
+    0's slice bit for bit (the other ranks contribute zeros there; the buffer is zeroed every step)."""
+    rec = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"], {"CIMRGP_BENCH_REHEARSAL": "gloo"})
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["config"]["backend"] == "gloo" and rec["config"]["rows_queues"] == 1
+    assert rec["reduce_selfcheck_max_abs_diff"] == 0.0
+
+
 def test_bench_step_under_rccl_world_of_one():
     """The real bench step with backend nccl (= RCCL) initialised and the fused [mean | var] buffer reduced
     through it unconditionally -- the only RCCL evidence obtainable on one GPU -- beside the plain run, with
