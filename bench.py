@@ -37,6 +37,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32-input MFMA peak
 
 import workloads
 
+EVENT_EVERY = 4          # timed steps whose trailing-update launches are bracketed by events (main)
 PMC_PROFILE = "r03_pmc_bench_n8192.json"
 
 
@@ -271,6 +272,9 @@ def main():
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-launch-events", action="store_true",
+                    help="do not bracket the trailing-update launches of the timed steps with events (measures what the "
+                         "roofline's live timing costs; the roofline then comes from the factorisations without carried rows only)")
     ap.add_argument("--cpu-warmups", type=int, default=3)
     ap.add_argument("--cpu-repeats", type=int, default=5)
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4],
@@ -391,10 +395,16 @@ def main():
     barrier()
     assert int(info.item()) == 0, "Cholesky failed in warm-up"
 
-    _lib.check(lib.cimrgp_profile_begin(), "cimrgp_profile_begin")
+    # The roofline's live timing: HIP events around the trailing-update launches, on their own stream, in every
+    # EVENT_EVERY-th timed step (two event records per launch on the update queue cost ~1 % of a step when every
+    # step carries them: 120.6 against 121.3-122.3 posteriors/s without any).
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if not args.no_launch_events and i % EVENT_EVERY == 0:
+            _lib.check(lib.cimrgp_profile_begin(), "cimrgp_profile_begin")
         step(True)
+        if i % EVENT_EVERY == 0:
+            _lib.check(lib.cimrgp_profile_pause(), "cimrgp_profile_pause")
         # stage times are read after the loop from the last step's events only
     drain()                                       # the last step's collective completes inside the timed region
     barrier()
@@ -464,7 +474,7 @@ def main():
                                                     "one persistent launch) and k_gemm_nt_sub<%s, lower, *>"
                                                     % (("double", "double") if args.dtype == "f64" else ("float", "float")),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "launches": int(tr_cnt.value),
+                         "launches": int(tr_cnt.value), "timed_steps_sampled": "every %d-th of %d" % (EVENT_EVERY, args.steps),
                          "avg_launch_ms": tr_ms.value / max(1, tr_cnt.value),
                          "avg_launch_gflop": tr_fl.value / max(1, tr_cnt.value) / 1e9,
                          "traffic": None,

@@ -55,6 +55,7 @@ SIGNATURES = {
     "cimrgp_tuning_build": (_i32, []),
     "cimrgp_shutdown": (_i32, []),
     "cimrgp_profile_begin": (_i32, []),
+    "cimrgp_profile_pause": (_i32, []),
     "cimrgp_profile_collect": (_i32, [C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_i64)]),
     "cimrgp_profile_collect_bytes": (_i32, [C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_i64)]),
 }

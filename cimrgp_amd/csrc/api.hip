@@ -529,6 +529,8 @@ int cimrgp_tuning_build(void)
 
 int cimrgp_profile_begin(void) { return profile_begin(); }
 
+int cimrgp_profile_pause(void) { return cimrgp::profile_pause(); }
+
 int cimrgp_profile_collect(double* total_ms, double* total_flops, int64_t* launches)
 {
     return profile_collect(total_ms, total_flops, launches);

@@ -141,6 +141,7 @@ template <typename T> int solve_rows_run(const T* l, int64_t n, int64_t ld, cons
                                          int64_t ldb, hipStream_t st, PotrfBatch bt = PotrfBatch());
 int potrf_shutdown();     // destroys the look-ahead contexts (streams, events): cimrgp_shutdown
 int profile_begin();
+int profile_pause();
 int profile_collect(double* total_ms, double* total_flops, int64_t* launches, double* total_bytes = nullptr);
 // gemm_nt.hip
 // A batch of independent products in one launch (equal shapes; element strides between problems).

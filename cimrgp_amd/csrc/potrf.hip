@@ -38,6 +38,15 @@ int profile_begin()
     return 0;
 }
 
+// Stops recording without touching the records so far (profile_begin resumes): bench.py brackets the launches of
+// every fourth step only -- two event records per launch on the update queue cost ~1 % of an N = 8192 step.
+int profile_pause()
+{
+    std::lock_guard<std::mutex> guard(g_profile_mutex);
+    g_profile = false;
+    return 0;
+}
+
 int profile_collect(double* total_ms, double* total_flops, int64_t* launches, double* total_bytes)
 {
     std::lock_guard<std::mutex> guard(g_profile_mutex);

@@ -305,6 +305,7 @@ int cimrgp_shutdown(void);
  * flops (M (M+1) K per launch) and the number of launches.
  * HOST pointers.  Not thread-safe; meant for one benchmarking thread. */
 int cimrgp_profile_begin(void);
+int cimrgp_profile_pause(void);   /* stop recording, keep the records (cimrgp_profile_begin resumes) */
 int cimrgp_profile_collect(double* total_ms, double* total_flops, int64_t* launches);
 /* the same, plus the summed ALGORITHMIC bytes of those launches: C (lower triangle) read and written
  * once, the K-wide panel read once -- (M (M + 1) + M K) x element size per launch. */
