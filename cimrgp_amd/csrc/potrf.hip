@@ -1938,6 +1938,7 @@ struct LookAhead {
     std::vector<hipEvent_t> ev;
     int* flag = nullptr;               // device counter: head tiles stored by the combined update launches (k_gate polls it)
     hipStream_t owner = nullptr;       // the caller stream this context was created for
+    bool gate_ok = false;              // this context may hold a kernel that waits for another one (k_gate): the device's first context only
     std::mutex enqueue;                // one factorisation at a time enqueues on this context's queues
 };
 std::mutex g_reg_mutex;                // guards g_ctx and context creation
@@ -1988,6 +1989,10 @@ LookAhead* acquire_ctx(hipStream_t st)
         LookAhead* la = make_ctx(dev);
         if (la == nullptr) return list.empty() ? nullptr : list[0];
         la->owner = st;
+        // One context per device may use the gate.  Streams share the runtime's four hardware queues; with two
+        // gate users a gate of A could sit in front of the update B's gate waits for and vice versa.  Within one
+        // context the update is always enqueued ahead of its gate, so a single user cannot block itself.
+        la->gate_ok = list.empty();
         list.push_back(la);
         return la;
     }
@@ -2280,7 +2285,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
         // (not while the carried rows are running: their kernels hold compute units the persistent workgroups
         // of the combined launch -- head tiles included -- would have to wait for: 114 -> 109 posteriors/s)
         const bool rows_running = rows && !rows_fused && (n - k1 <= knobs().rows_start_below);
-        const int heads = (knobs().chain_mode == 0 && !rows_running && w == CIMRGP_NB && wn == CIMRGP_NB && n > k2 && !grp_open() &&
+        const int heads = (la->gate_ok && knobs().chain_mode == 0 && !rows_running && w == CIMRGP_NB && wn == CIMRGP_NB && n > k2 && !grp_open() &&
                            group_size(n - k2 - ((n - k2 < CIMRGP_NB) ? (n - k2) : CIMRGP_NB), knobs().far_pair_above) == 1)
                               ? gemm_pers_head_tiles(n - k1, (int)w, (int)sizeof(T)) : 0;
         if (heads > 0) {
