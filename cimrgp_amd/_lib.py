@@ -25,6 +25,8 @@ SIGNATURES = {
     "cimrgp_potrf_workspace_bytes": (_sz, [_i32, _i64]),
     "cimrgp_potrf": (_i32, [_i32, _vp, _i64, _i64, _vp, _sz, _vp, _vp]),
     "cimrgp_potrf_rows": (_i32, [_i32, _vp, _i64, _i64, _vp, _sz, _vp, _vp, _i64, _i64, _vp]),
+    "cimrgp_block_posterior": (_i32, [_i32, _vp, _i64, _i32, _vp, _i32, _vp, _i64, _dbl, _dbl, _dbl, _vp, _i64, _vp, _sz, _vp, _vp, _i64,
+                                      _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "cimrgp_potrf_rows_batched": (_i32, [_i32, _vp, _i64, _i64, _i64, _vp, _sz, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
     "cimrgp_solve_lt_batched": (_i32, [_i32, _vp, _i64, _i64, _i64, _vp, _sz, _vp, _i32, _vp, _i32, _vp]),
     "cimrgp_solve_lt": (_i32, [_i32, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _vp]),

@@ -106,6 +106,37 @@ static int layer_predict_typed(const void* x, const int64_t* starts, int64_t n, 
     return layer_predict_run<T>(a, st);
 }
 
+namespace cimrgp {
+// (layer.hip) the targets as carried rows, rows[c][j] = y[j][c]; and back: z[j][c] = alpha[j][c] = rows[c][j]
+template <typename T> int rhs_rows_run(const T* y, int64_t n, int q, T* rows, int64_t ldr, hipStream_t st);
+template <typename T> int rows_to_z_run(const T* rows, int64_t ldr, int64_t n, int q, T* z, T* alpha, hipStream_t st);
+}  // namespace cimrgp
+
+namespace {
+// cimrgp_block_posterior: the separate entry points' work in one call, in their order.  (Measured and not kept: the
+// Gram matrix right of the first panel and the carried rows written BESIDE the first panel's chain -- the chain's
+// first diagonal block then took 59-64 us instead of 16-20 under the write traffic and the step got no shorter:
+// HISTORY.md.)
+template <typename T>
+int block_posterior_typed(const void* x, int64_t n, int d, const void* y, int q, const void* xs, int64_t ns, double ell, double sf2,
+                          double noise, void* k, int64_t ldk, void* ws, int32_t* info, void* w, int64_t ldw, void* alpha, void* z,
+                          void* scratch, void* mean, void* var, int add_noise, int accumulate, hipStream_t st)
+{
+    using namespace cimrgp;
+    T* wt = (T*)w;
+    int rc = rbf_gram_run<T>((const T*)x, n, (const T*)x, n, d, ell, sf2, noise, (T*)k, ldk, true, true, st);
+    if (!rc && ns > 0) rc = rbf_gram_run<T>((const T*)xs, ns, (const T*)x, n, d, ell, sf2, 0.0, wt, ldw, false, false, st);
+    if (!rc) rc = rhs_rows_run<T>((const T*)y, n, q, wt + ns * ldw, ldw, st);
+    if (!rc) rc = potrf_run<T>((T*)k, n, ldk, (T*)ws, info, wt, ns + q, ldw, st);
+    // z = L^-1 y (the last q carried rows), alpha = L^-T z, mean = W z, var = sf2 - sum W^2 (+ noise)
+    if (!rc) rc = rows_to_z_run<T>(wt + ns * ldw, ldw, n, q, (T*)z, (T*)alpha, st);
+    if (!rc) rc = potrs_run<T>((const T*)k, n, ldk, (const T*)ws, (T*)alpha, q, nullptr, (T*)scratch, true, st);
+    if (!rc && ns > 0) rc = predict_from_w_run<T>((const T*)w, ns, n, ldw, (const T*)z, q, sf2, add_noise ? noise : 0.0, nullptr, nullptr,
+                                                   (T*)mean, (T*)var, accumulate, st, 1, nullptr, 0);
+    return rc;
+}
+}  // namespace
+
 extern "C" {
 
 int cimrgp_version(void) { return 100; }
@@ -182,6 +213,27 @@ int cimrgp_potrf_rows(int dtype, void* k_dev, int64_t n, int64_t ldk, void* work
     DISPATCH(dtype, fn,
              potrf_run<float>((float*)k_dev, n, ldk, (float*)workspace_dev, info_dev, (float*)b_dev, m, ldb, S(stream)),
              potrf_run<double>((double*)k_dev, n, ldk, (double*)workspace_dev, info_dev, (double*)b_dev, m, ldb, S(stream)));
+}
+
+int cimrgp_block_posterior(int dtype, const void* x_dev, int64_t n, int d, const void* y_dev, int q, const void* xs_dev, int64_t ns,
+                           double ell, double sf2, double noise, void* k_dev, int64_t ldk, void* workspace_dev,
+                           size_t workspace_bytes, int32_t* info_dev, void* w_dev, int64_t ldw, void* alpha_dev, void* z_dev,
+                           void* scratch_dev, void* mean_dev, void* var_dev, int add_noise, int accumulate, void* stream)
+{
+    const char* fn = "cimrgp_block_posterior";
+    CIMRGP_REQUIRE(x_dev && y_dev && k_dev && workspace_dev && info_dev && w_dev && alpha_dev && z_dev && scratch_dev, fn, "null pointer");
+    CIMRGP_REQUIRE(ns == 0 || (xs_dev && mean_dev && var_dev), fn, "null pointer (test points)");
+    CIMRGP_REQUIRE(n >= 1 && ns >= 0 && ldk >= n && ldw >= n, fn, "bad dimensions");
+    CIMRGP_REQUIRE(q >= 1 && q <= 8, fn, "number of outputs must be in [1, 8]");
+    CIMRGP_REQUIRE(dtype == CIMRGP_F32 || dtype == CIMRGP_F64, fn, "unknown dtype");
+    CIMRGP_REQUIRE(ld_ok(dtype, ldk) && ld_ok(dtype, ldw), fn, "leading dimensions must be multiples of 16 bytes");
+    CIMRGP_REQUIRE(aligned16(k_dev) && aligned16(workspace_dev) && aligned16(w_dev), fn, "pointers must be 16-byte aligned");
+    CIMRGP_REQUIRE(workspace_bytes >= cimrgp_potrf_workspace_bytes(dtype, n), fn, "workspace too small");
+    DISPATCH(dtype, fn,
+             block_posterior_typed<float>(x_dev, n, d, y_dev, q, xs_dev, ns, ell, sf2, noise, k_dev, ldk, workspace_dev, info_dev, w_dev, ldw,
+                                          alpha_dev, z_dev, scratch_dev, mean_dev, var_dev, add_noise, accumulate, S(stream)),
+             block_posterior_typed<double>(x_dev, n, d, y_dev, q, xs_dev, ns, ell, sf2, noise, k_dev, ldk, workspace_dev, info_dev, w_dev, ldw,
+                                           alpha_dev, z_dev, scratch_dev, mean_dev, var_dev, add_noise, accumulate, S(stream)));
 }
 
 int cimrgp_potrf_rows_batched(int dtype, void* k_dev, int64_t n, int64_t ldk, int64_t k_stride, void* workspace_dev,

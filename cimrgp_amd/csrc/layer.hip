@@ -183,6 +183,39 @@ int layer_predict_run(const LayerPredict<T>& a, hipStream_t st)
                                  a.batch, a.t_starts, a.sw);
 }
 
+// The targets of ONE block as carried rows and back (cimrgp_block_posterior).
+template <typename T>
+__global__ void k_rhs_rows(const T* __restrict__ y, int64_t n, int q, T* __restrict__ rows, int64_t ldr)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * q) return;
+    const int64_t j = e / q;
+    const int c = (int)(e - j * q);
+    rows[(int64_t)c * ldr + j] = y[e];
+}
+
+template <typename T>
+int rhs_rows_run(const T* y, int64_t n, int q, T* rows, int64_t ldr, hipStream_t st)
+{
+    if (n <= 0 || q <= 0) return 0;
+    hipLaunchKernelGGL((k_rhs_rows<T>), dim3((unsigned)((n * q + 255) / 256)), dim3(256), 0, st, y, n, q, rows, ldr);
+    CIMRGP_LAUNCH_CHECK("cimrgp_block_posterior");
+    return 0;
+}
+
+template <typename T>
+int rows_to_z_run(const T* rows, int64_t ldr, int64_t n, int q, T* z, T* alpha, hipStream_t st)
+{
+    if (n <= 0 || q <= 0) return 0;
+    hipLaunchKernelGGL((k_layer_z<T>), dim3((unsigned)((n * q + 255) / 256), 1), dim3(256), 0, st, rows, ldr, (int64_t)0, n, q, z, alpha);
+    CIMRGP_LAUNCH_CHECK("cimrgp_block_posterior");
+    return 0;
+}
+
+template int rhs_rows_run<double>(const double*, int64_t, int, double*, int64_t, hipStream_t);
+template int rhs_rows_run<float>(const float*, int64_t, int, float*, int64_t, hipStream_t);
+template int rows_to_z_run<double>(const double*, int64_t, int64_t, int, double*, double*, hipStream_t);
+template int rows_to_z_run<float>(const float*, int64_t, int64_t, int, float*, float*, hipStream_t);
 template int layer_fit_run<double>(const LayerFit<double>&, hipStream_t);
 template int layer_fit_run<float>(const LayerFit<float>&, hipStream_t);
 template int layer_predict_run<double>(const LayerPredict<double>&, hipStream_t);

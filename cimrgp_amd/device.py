@@ -122,6 +122,23 @@ def potrf_rows(kbuf, n, bbuf, m, ws=None, info=None):
     return ws, info
 
 
+def block_posterior(x, y, xs, ell, sf2, noise, kbuf, wbuf, ws, info, alpha, z, mean, var, add_noise=False, accumulate=False):
+    """One block's whole posterior in ONE call (cimrgp_block_posterior, include/cimrgp.h): Gram matrix, factorisation with
+    the cross-Gram rows and the targets carried, backward solve, predictive mean and variance -- the same kernels as the
+    separate calls.  kbuf (n x ld), wbuf ((ns + q) x ld), ws / info as for potrf; alpha, z (n x q),
+    mean (ns x q), var (ns) are filled."""
+    lib = _lib.load()
+    n, d = x.shape
+    q = y.shape[1]
+    ns = 0 if xs is None else xs.shape[0]
+    scratch = torch.empty(2 * q * max(int(n), 1), dtype=x.dtype, device=x.device)
+    _lib.check(lib.cimrgp_block_posterior(_DT[x.dtype], _p(x), int(n), int(d), _p(y), int(q), _p(xs), int(ns), float(ell), float(sf2),
+                                          float(noise), _p(kbuf), kbuf.stride(0), _p(ws), ws.numel(), _p(info), _p(wbuf),
+                                          wbuf.stride(0), _p(alpha), _p(z), _p(scratch), _p(mean), _p(var), int(bool(add_noise)),
+                                          int(bool(accumulate)), _stream()), "cimrgp_block_posterior")
+    return mean, var
+
+
 def potrf_rows_batched(karena, n, ld, ws_arena, info, barena=None, m=0, ldb=0):
     """``batch`` equal-sized factorisations in the same launches.  karena: (batch, n, ld) tensor,
     ws_arena: (batch, ws_bytes) uint8, info: (batch,) int32, barena: (batch, m, ldb) carried rows."""

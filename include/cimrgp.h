@@ -87,6 +87,21 @@ int cimrgp_potrf_rows(int dtype, void* k_dev, int64_t n, int64_t ldk,
                       int32_t* info_dev, void* b_dev, int64_t m, int64_t ldb,
                       void* stream);
 
+/* One block's whole posterior in ONE call -- SURVEY section 8b's fused entry: what GPy.models.GPRegression(x, y,
+ * RBF) + model.predict(xs) do behind src/RegressionInput.py:60-67 (variance:
+ * scripts/tests/GPRBF_vs_ciMRGP_vs_fiMRGP.py:121):
+ *   K = sf2 exp(-|x - x'|^2 / (2 ell^2)) + noise I -> L L^T in k_dev (n x ldk, lower), workspace / info_dev as cimrgp_potrf;
+ *   W = K(xs, x) L^-T in the first ns rows of w_dev ((ns + q) x ldw; its last q rows hold z^T afterwards);
+ *   z_dev (n x q) = L^-1 y, alpha_dev (n x q) = K^-1 y (scratch_dev: 2 q n elements);
+ *   mean_dev (ns x q) (+)= W z, var_dev (ns) (+)= sf2 - sum W^2 (+ noise if add_noise).
+ * The same kernels as cimrgp_rbf_gram + cimrgp_rbf_cross + cimrgp_potrf_rows + cimrgp_solve_lt +
+ * cimrgp_predict_from_w, in that order, with bit-identical results: one call for a ctypes-only caller. */
+int cimrgp_block_posterior(int dtype, const void* x_dev, int64_t n, int d, const void* y_dev, int q,
+                           const void* xs_dev, int64_t ns, double ell, double sf2, double noise,
+                           void* k_dev, int64_t ldk, void* workspace_dev, size_t workspace_bytes,
+                           int32_t* info_dev, void* w_dev, int64_t ldw, void* alpha_dev, void* z_dev,
+                           void* scratch_dev, void* mean_dev, void* var_dev, int add_noise,
+                           int accumulate, void* stream);
 /* `batch` equal-sized factorisations -- the blocks of one layer (independent over regions,
  * Posteriors.py:35-59) -- in the SAME kernel launches: matrix i starts k_stride elements after
  * matrix i-1 (likewise workspace_stride_bytes, b_stride), info_dev holds `batch` int32.  One queue

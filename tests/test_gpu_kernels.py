@@ -376,3 +376,48 @@ def test_potrf_rows_batched_matches_single(dev, dt, tol, n, batch, m):
         dev.potrf_rows_batched(karena, n, ld, ws_arena, info)
         got = info.cpu().tolist()
         assert got[1] > 0 and all(g == 0 for j, g in enumerate(got) if j != 1)
+
+
+@pytest.mark.parametrize("n,ns,q,d", [(300, 70, 2, 2), (1100, 130, 3, 1), (5377, 70, 2, 1), (6000, 260, 1, 2)])
+def test_block_posterior_one_call_matches_the_separate_calls_and_the_oracle(dev, n, ns, q, d):
+    """cimrgp_block_posterior: Gram, factorisation with the cross-Gram rows and the targets carried, backward solve,
+    predictive mean and variance in ONE call -- bit for bit what the separate calls give, and the oracle's
+    posterior; one-queue sizes and the look-ahead schedule with ragged last panels."""
+    rng = np.random.default_rng(n + ns)
+    x = rng.uniform(-2.0, 2.0, size=(n, d))
+    x = x[np.argsort(x[:, 0])]
+    y = np.stack([np.sin(2 * x[:, 0] + c) for c in range(q)], axis=1) + 0.1 * rng.normal(size=(n, q))
+    xs = rng.uniform(-2.0, 2.0, size=(ns, d))
+    ell, sf2, noise = 0.3 if d == 2 else 0.05, 1.2, 0.02
+    tdt = torch.float64
+    xd, yd, xsd = (dev.to_device(a, tdt, "cuda") for a in (x, y, xs))
+    kbuf = dev.alloc_matrix(n, n, tdt, "cuda")
+    wbuf = dev.alloc_matrix(ns + q, n, tdt, "cuda")
+    ws = dev.potrf_workspace(n, tdt, "cuda")
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    alpha = torch.zeros((n, q), dtype=tdt, device="cuda")
+    z = torch.zeros((n, q), dtype=tdt, device="cuda")
+    mean = torch.zeros((ns, q), dtype=tdt, device="cuda")
+    var = torch.zeros(ns, dtype=tdt, device="cuda")
+    dev.block_posterior(xd, yd, xsd, ell, sf2, noise, kbuf, wbuf, ws, info, alpha, z, mean, var)
+    assert int(info.item()) == 0
+    # the separate calls
+    k2 = dev.rbf_gram(xd, ell, sf2, noise, lower_only=True)
+    w2 = dev.alloc_matrix(ns + q, n, tdt, "cuda")
+    dev.rbf_cross(xsd, xd, ell, sf2, out=w2)
+    w2[ns:ns + q, :n] = yd.t()
+    ws2, info2 = dev.potrf_rows(k2, n, w2, ns + q)
+    z2 = w2[ns:ns + q, :n].t().contiguous()
+    a2 = dev.solve_lt(k2, n, ws2, z2.clone())
+    m2 = torch.zeros_like(mean)
+    v2 = torch.zeros_like(var)
+    dev.predict_from_w(w2, ns, n, z2, sf2, 0.0, None, m2, v2, accumulate=False)
+    assert torch.equal(torch.tril(kbuf[:n, :n]), torch.tril(k2[:n, :n]))
+    assert torch.equal(wbuf[:ns + q, :n], w2[:ns + q, :n])
+    assert torch.equal(z, z2) and torch.equal(alpha, a2) and torch.equal(mean, m2) and torch.equal(var, v2)
+    # the oracle
+    fit = oracle.block_fit(x, y, ell, sf2, noise)
+    om, ov = oracle.block_predict(x, fit, xs, ell, sf2, True)
+    assert _relerr(alpha.cpu().numpy(), fit["alpha"]) < 1e-8
+    assert _relerr(mean.cpu().numpy(), om) < 1e-8
+    assert float(np.max(np.abs(var.cpu().numpy() - ov))) / sf2 < 1e-9
