@@ -229,6 +229,8 @@ class MultiResolutionGaussianProcess(object):
         if np.any(flags != 0.0):
             j = int(np.flatnonzero(flags != 0.0)[0])
             self.posterior_obj[j].check(self._owned(j))      # the owner reports the leading minor
+            if dev.is_watchdog(flags[j]):                    # a schedule failure on another rank: not "not PD"
+                raise RuntimeError('cimrgp_potrf: schedule watchdog (a block of layer %d owned by another rank)' % j)
             raise np.linalg.LinAlgError('Matrix is not positive definite (a block of layer %d '
                                         'owned by another rank)' % j)
         self._f_bar_final = f_bar

@@ -260,6 +260,10 @@ template <> __device__ __forceinline__ float rsqrt_refined<float>(float d)
     return fmaf(0.5f * r, e, r);
 }
 
+// hardware reciprocal estimate (v_rcp_f64 / v_rcp_f32): the pivot recurrence refines it itself
+static __device__ __forceinline__ double rcp_seed(double d) { return __builtin_amdgcn_rcp(d); }
+static __device__ __forceinline__ float rcp_seed(float d) { return __builtin_amdgcn_rcpf(d); }
+
 // ---------------------------------------------------------------------------
 // Riders (round 3).  The launches of a panel's chain are latency-bound: one workgroup factors a 64 x 64
 // block for 17-31 us while the 30-250 panel-solve workgroups beside it are gone after ~10 us and most
@@ -342,9 +346,16 @@ static __device__ __forceinline__ void run_rider(unsigned char* smem, const Ride
 // ---------------------------------------------------------------------------
 // LDS-only barrier: waits for this wave's LDS traffic, not for global stores in
 // flight (a plain __syncthreads() also drains vmcnt, i.e. every store's round trip).
+// Round 4: a real fence pair restricted to the LDS address space, not inline assembly.  The instructions are the same
+// (s_waitcnt lgkmcnt(0); s_barrier), but the compiler did not treat the assembly's "memory" clobber as a write to
+// __shared__ arrays whose address never leaves the kernel: with the pivot loop unrolled it kept a tile wave's
+// left operand, read from LDS two barriers earlier at the same address, in registers (the pivot wave had
+// rewritten it in between).  Fences are what __syncthreads() is made of and do order such accesses.
 static __device__ __forceinline__ void lds_barrier()
 {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 // S and Mi are held as ONE combined 64x64 array A:
@@ -387,24 +398,44 @@ static __device__ __forceinline__ Mx<float>::acc_t mfma_k4(float a, float b, Mx<
 // scalar FMAs whose per-column coefficients every wave read as LDS broadcasts: 2 MB of LDS
 // return traffic per block, 1.1 us per 4 pivots of which the pivots themselves were 0.24 us.)
 // One block of BC = 4 pivots in the pivot wave (lane = row i), shared by the nine-wave and the four-wave
-// factorisation: takes the block's columns `nx` as gathered (updated through block p-2), applies block
-// p-1's rank-4 update to them itself, eliminates the 4 pivots and publishes the rank-4 update's two
-// operands (hs_row: this row's left operand; cs: the pivot-time columns, kept for all 64 pivots) and the
-// reciprocal roots.  Returns 1 + the first non-positive pivot of the block (0: none).
+// factorisation: takes the block's columns `nx` as gathered (updated through block p-2; rows of block p-1
+// gathered as ZERO: their slots restart there), applies block p-1's rank-4 update to them itself, eliminates
+// the 4 pivots and publishes the rank-4 update's two operands (hs_row: this row's left operand, UNMASKED --
+// the tile waves zero the three entries of a block's own rows that lie below their pivots; cs: the
+// pivot-time columns, kept for all 64 pivots).
+//
+// Round 4: this wave is ISSUE-bound, not latency-bound.  A lone wave issues one instruction per ~5 clocks
+// (tools/diag_probe.hip: 4 pivots = 750-790 clocks with an 11-deep dependent chain per pivot and just the
+// same with a 5-deep one), and an iteration of rounds 1-3 was ~300 instructions of this wave against ~500
+// clocks of the tile waves' work.  So everything that is not the recurrence left the loop:
+//   * the recurrence needs -A[i][j] / d only: a reciprocal (seed + three fused steps, x0 (1 + e)(1 + e^2)),
+//     no root.  The reciprocal roots -- which only scale the OUTPUT -- and the first non-positive pivot are
+//     taken after the loop from the pivots themselves, d_j = cs[j][j] (a pivot-time column is final from
+//     its own pivot on): diag_roots;
+//   * row j itself takes the generic -A[j][j] / d = -1 instead of -1/d, i.e. column i of the unscaled
+//     inverse is kept scaled by d_i (its birth needs no division and no select; the recurrence of an
+//     inverse column is linear in it; the epilogue multiplies by r_i^2): no special case for lane j;
+//   * "restart from zero" of a slot is one select on the high word (tiny_if): as an addend a double
+//     below 2^-1042 is zero.
+template <typename T> static __device__ __forceinline__ T tiny_if(T v, bool c);
+template <> __device__ __forceinline__ double tiny_if<double>(double v, bool c)
+{
+    return __hiloint2double(c ? 0 : __double2hiint(v), __double2loint(v));
+}
+template <> __device__ __forceinline__ float tiny_if<float>(float v, bool c) { return c ? 0.0f : v; }
+
 template <typename T>
-static __device__ __forceinline__ int pivot_block(int p, T (&nx)[4], T (&cv)[4], T (&rr)[4], T (&hsr)[4],
-                                                   T* __restrict__ hs_row, T* __restrict__ cs, T* __restrict__ rall, int i, int w)
+static __device__ __forceinline__ void pivot_block(int p, T (&nx)[4], T (&cv)[4], T (&hsr)[4],
+                                                    T* __restrict__ hs_row, T* __restrict__ cs, int i)
 {
     constexpr int LS = SB + 2;
     constexpr int BC = 4;
     const int j0 = BC * p;
     if (p > 0) {
         // block p-1's update of block p's columns (the tile waves have not applied it to what was
-        // gathered); rows of block p-1 restart from 0
-        const bool prev_rows = (i >= j0 - BC) && (i < j0);
-        // the 4 x 4 coefficients = block p-1's pivot-time columns at the rows of block p: this wave
-        // published them in `cs` before the barrier; 8 uniform 16-byte LDS reads, in flight together
-        // with the gathered columns, instead of 32 v_readlane from its own registers
+        // gathered).  The 4 x 4 coefficients = block p-1's pivot-time columns at the rows of block p: this
+        // wave published them in `cs` before the barrier; 8 uniform 16-byte LDS reads, in flight together
+        // with the gathered columns.  One chain of four fused operations per column (fewest instructions).
         const T* sp = &cs[j0 * LS + j0 - BC];
         T sm[BC][BC];
 #pragma unroll
@@ -413,143 +444,273 @@ static __device__ __forceinline__ int pivot_block(int p, T (&nx)[4], T (&cv)[4],
             for (int t = 0; t < BC; ++t) sm[t2][t] = sp[t2 * LS + t];
 #pragma unroll
         for (int t2 = 0; t2 < BC; ++t2) {
-            T u = hsr[0] * sm[t2][0];
+            T u = nx[t2];
 #pragma unroll
-            for (int t = 1; t < BC; ++t) u = fma(hsr[t], sm[t2][t], u);
-            nx[t2] = prev_rows ? u : nx[t2] + u;
+            for (int t = 0; t < BC; ++t) u = fma(hsr[t], sm[t2][t], u);
+            nx[t2] = u;
         }
     }
 #pragma unroll
     for (int t = 0; t < BC; ++t) cv[t] = nx[t];
     if (p == 8) STAMPW(17, DG_TW);
-    int bad = 0;
-    const bool in_block = (i >= j0) && (i < j0 + BC);
+    T nh[BC];
 #pragma unroll
     for (int t = 0; t < BC; ++t) {
         const int j = j0 + t;
         const T d = bcast_lane(cv[t], j);
-        const T r = rsqrt_refined<T>(d);
-        rr[t] = r;
-        const T h = (i == j) ? r : cv[t] * r;
-        const T nhr = -h * r;
+        const T x0 = rcp_seed(d);
+        const T e = fma(-d, x0, (T)1);
+        const T sx0 = -cv[t] * x0;
+        const T sx1 = fma(sx0, e, sx0);
+        nh[t] = fma(sx1, e * e, sx1);                                // -A[i][j] / d  (row j: -1)
 #pragma unroll
         for (int t2 = t + 1; t2 < BC; ++t2) {
             const T ak = bcast_lane(cv[t], j0 + t2);                // A[k][j] at pivot time
-            cv[t2] = fma(nhr, ak, (i == j) ? (T)0 : cv[t2]);
+            cv[t2] = fma(nh[t], ak, tiny_if<T>(cv[t2], i == j));    // row j: its slots right of the pivot are born here
         }
-        if (!(d > (T)0) && bad == 0 && j < w) bad = j + 1;          // uniform: d is a broadcast value
-        hsr[t] = (in_block && i > j) ? (T)0 : nhr;
     }
     if (p == 8) STAMPW(18, DG_TW);
     T* cp = &cs[i * LS + j0];
 #pragma unroll
     for (int t = 0; t < BC; ++t) {
-        hs_row[t] = hsr[t];
+        hs_row[t] = nh[t];
         cp[t] = cv[t];
     }
-    if (i < BC) rall[j0 + i] = (i == 0) ? rr[0] : (i == 1) ? rr[1] : (i == 2) ? rr[2] : rr[3];
+    // this wave's own copy of the left operand, for the next block's self-update: a row of THIS block takes
+    // nothing from the pivots above it (its slots right of the block are born at its own pivot)
+    const unsigned u = (unsigned)(i - j0);
+    hsr[0] = tiny_if<T>(nh[0], u - 1u < 3u);
+    hsr[1] = tiny_if<T>(nh[1], u - 2u < 2u);
+    hsr[2] = tiny_if<T>(nh[2], u == 3u);
+    hsr[3] = nh[3];
     if (p == 8) STAMPW(19, DG_TW);
-    return bad;
 }
 
-// The factorisation proper, shared by k_diag64 and k_link: on entry the tile waves hold the Schur
-// complement S (identity-padded, strict upper part zero) in accumulator layout; `pcol`, `hs`, `cs`,
-// `rall` are LDS areas nobody reads any more (they may overlay operand tiles of the caller once all
-// waves have passed the first barrier below).  Writes L into D (lower) and L^-1 into `inv`.
+// After the pivot loop (all waves past a barrier): the reciprocal roots r_j = 1 / sqrt(d_j) from the pivots
+// d_j = cs[j][j], and the first non-positive pivot among the block's w columns.  One wave, lane = j.
+template <typename T>
+static __device__ __forceinline__ void diag_roots(const T* __restrict__ cs, T* __restrict__ rall, int lane, int w,
+                                                   int32_t* info, int col_base)
+{
+    constexpr int LS = SB + 2;
+    const T d = cs[lane * LS + lane];
+    rall[lane] = rsqrt_refined<T>(d);
+    const unsigned long long badmask = __ballot(lane < w && !(d > (T)0));
+    if (badmask != 0ull && lane == 0) atomicCAS(info, 0, col_base + __ffsll((long long)badmask));
+}
+
+// The factorisation proper, shared by all four chain kernels.  On entry `cs` holds the Schur complement S
+// (lower triangle, identity padding beyond w, zeros above the diagonal) and every wave has passed a barrier
+// behind its writer; `pcol`, `hs`, `rall` are LDS areas nobody reads any more.  Writes L into D (lower) and
+// L^-1 into `inv`.
+//   tw >= 0   tile wave number tw of NTW: owns the 16 x 16 tiles t = tw + NTW k of the combined array
+//             (t = 4 row-tile + column-tile) in matrix-core accumulator layout;
+//   pivot     the pivot wave (pivot_block);
+//   neither   keeps the barriers only.
+// Round 4: WHICH SIMD the pivot wave shares matters more than how many tile waves there are.  The vector ALU
+// of a SIMD issues one wave-wide instruction per 4 clocks whatever wave it comes from, and the pivot wave's
+// ~140 instructions per block of 4 pivots are the critical path: with two tile waves on its SIMD (rounds 1-3:
+// nine waves, waves 0 / 4 / 8 on SIMD 0) an iteration took the SUM of the pivot wave's and the tile waves'
+// issue time (tools/diag_probe.hip, 200 launches back to back: 13.5 us per kernel; tile waves idle 10.1;
+// pivot wave idle 7.5).  So the nine-wave kernels leave waves 0 and 4 idle in the loop and deal the sixteen
+// tiles to the six waves of the other three SIMDs (nine_tile_wave), the four-wave kernels keep three tile
+// waves beside a pivot wave with a SIMD of its own.
+// Tile ownership: a tile wave owns tiles of ONE 16-column block BCOL (two in the four-wave form's last wave), rows
+// BR0 .. BR0 + NB - 1.  All its tiles then share the right operand, are final together (one uniform early-out per
+// block of pivots), and its step is straight-line code: every operand is requested before the first multiply
+// (with the sixteen tiles dealt round-robin, each tile sat behind its own branches and paid its own LDS round
+// trip: 240 clocks per tile, 14.3 us per kernel with the pivot wave idle against 7.5 for two tiles per wave).
+// Each role runs its OWN copy of the pivot loop (same number of barriers): with the roles told apart inside one
+// loop the compiler moved the accumulators between per-branch register assignments every iteration.
+//   nine-wave kernels (6 tile waves): column 3: rows 0-1 | 2-3, column 2: rows 0-1 | 2-3, column 1: all, column 0: all
+//   four-wave kernels (3 tile waves): column 3 | column 2 | columns 1 and 0
+template <typename T, int NB, int BCOL, int BR0>
+struct TileGroup {
+    using X = Mx<T>;
+    using acc_t = typename X::acc_t;
+    static constexpr int LS = SB + 2;
+    static constexpr int BC = 4;
+    static constexpr int NP = SB / BC;
+    acc_t acc[NB > 0 ? NB : 1];
+    __device__ __forceinline__ void load(const T* cs, int lane)
+    {
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[k][r] = cs[((BR0 + k) * 16 + X::crow(lane, r)) * LS + BCOL * 16 + (lane & 15)];
+    }
+    // block p's rank-4 update of the group's tiles, then the gather of block p+2 (updated through block p):
+    //   right operand = the pivot-time columns at this column block's rows (zero for columns that are final),
+    //   left operand per tile = the pivot wave's -A[i][j] / d (a row of the block takes nothing from the pivots
+    //   above it: the pivot wave publishes unmasked),
+    //   rows of the block: their slots right of it restart from 0 (the one tile concerned: a uniform branch
+    //   ahead of the operand reads, so that no join sits between the reads and the multiplies).
+    // (no __restrict__ on these: `hs` and `cs` are rewritten by the PIVOT wave between the barriers, at addresses
+    // that repeat every second block -- a tile wave that only reads them must not be told they are its own)
+    __device__ __forceinline__ void step(int p, const T* hs, const T* cs, T* pcol, int lane)
+    {
+        if (NB == 0) return;
+        const int j0 = BC * p, bc0 = j0 >> 4, jb = j0 & 15;
+        if (BCOL < bc0) return;                                   // uniform: every column of the group is final
+        const int fcol = lane & 15, fk = lane >> 4;
+        const int col = BCOL * 16 + fcol;
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+            if (BR0 + k == bc0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rin = X::crow(lane, r);
+                    if (rin >= jb && rin < jb + BC && col >= j0 + BC) acc[k][r] = (T)0;
+                }
+            }
+        const T* hsp = hs + ((p & 1) * SB) * BC + fk;
+        T bf = cs[col * LS + j0 + fk];
+        T af[NB > 0 ? NB : 1];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) af[k] = hsp[((BR0 + k) * 16 + fcol) * BC];
+        if (col < j0 + BC) bf = (T)0;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int arow = (BR0 + k) * 16 + fcol;
+            if (arow > j0 + fk && arow < j0 + BC) af[k] = (T)0;
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) acc[k] = mfma_k4(af[k], bf, acc[k]);
+        const int g0 = j0 + 2 * BC, gbc = g0 >> 4, gjb = g0 & 15;   // block p+2
+        if (p + 2 < NP && BCOL == gbc && fcol >= gjb && fcol < gjb + BC) {
+            T* pc = pcol + ((p & 1) * SB) * BC + (fcol - gjb);
+#pragma unroll
+            for (int k = 0; k < NB; ++k)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // rows of block p+1 restart from zero in these columns (pivot_block adds to what it is given)
+                    const int grow = (BR0 + k) * 16 + X::crow(lane, r);
+                    pc[grow * BC] = (grow >= j0 + BC && grow < g0) ? (T)0 : acc[k][r];
+                }
+        }
+    }
+};
+
+// one tile wave's whole pivot loop (two groups; the second may be empty)
+template <typename T, int NB, int BCOL, int BR0, int NB2 = 0, int BCOL2 = 0, int BR02 = 0>
+static __device__ __forceinline__ void tile_wave_loop(const T* hs, const T* cs, T* pcol, int lane)
+{
+    TileGroup<T, NB, BCOL, BR0> ga;
+    TileGroup<T, NB2, BCOL2, BR02> gb;
+    ga.load(cs, lane);
+    if (NB2 > 0) gb.load(cs, lane);
+    lds_barrier();                                   // every wave has taken its share of S: cs may be overwritten
+    for (int p = 0; p < SB / 4; ++p) {
+        lds_barrier();
+#if defined(DIAG_EXP) && DIAG_EXP == 1
+        continue;
+#endif
+        ga.step(p, hs, cs, pcol, lane);
+        if (NB2 > 0) gb.step(p, hs, cs, pcol, lane);
+    }
+}
+
+template <typename T, int NTW, int NT>
+static __device__ __forceinline__ void diag_tail_lds(int tw, bool pivot, T* __restrict__ pcol, T* __restrict__ hs, T* __restrict__ cs,
+                                                      T* __restrict__ rall, T* __restrict__ D, int64_t ld,
+                                                      int w, T* __restrict__ inv, int32_t* info, int col_base)
+{
+    static_assert(NTW == 6 || NTW == 3, "tile ownership below");
+    constexpr int LS = SB + 2;       // even pitch: a row's 4 block columns are one 16-byte-aligned pair of stores
+    constexpr int BC = 4;
+    constexpr int NP = SB / BC;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int i = lane;
+    if (pivot) {
+        // ---- pivot wave: the recurrence and nothing else
+        T cv[BC], hsr[BC];                           // this row's block columns, left operand
+#pragma unroll
+        for (int t = 0; t < BC; ++t) { cv[t] = (T)0; hsr[t] = (T)0; }
+        T first[2][BC];                              // blocks 0 and 1 straight from S
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int t = 0; t < BC; ++t) first[b][t] = cs[i * LS + b * BC + t];
+        lds_barrier();                               // every wave has taken its share of S: cs may be overwritten
+        STAMP(2);
+        for (int p = 0; p < NP; ++p) {
+            if (p == 8) STAMPW(16, DG_TW);
+            T nx[BC];
+            if (p < 2) {
+#pragma unroll
+                for (int t = 0; t < BC; ++t) nx[t] = (p == 0) ? first[0][t] : first[1][t];
+            } else {
+                // this row's share of block p as gathered (two 16-byte reads, in flight during the FMAs below)
+                const T* gp = &pcol[((p & 1) * SB + i) * BC];
+#pragma unroll
+                for (int t = 0; t < BC; ++t) nx[t] = gp[t];
+            }
+#if !defined(DIAG_EXP) || DIAG_EXP != 2      /* timing-only builds of tools/diag_probe.hip: 1 = tile waves idle, 2 = pivot wave idle */
+            pivot_block<T>(p, nx, cv, hsr, &hs[((p & 1) * SB + i) * BC], cs, i);
+#endif
+            lds_barrier();
+            if (p == 8) STAMPW(20, DG_TW);
+            if (p == 9) STAMPW(21, DG_TW);
+        }
+    } else if (tw < 0) {
+        lds_barrier();
+        for (int p = 0; p < NP; ++p) lds_barrier();
+    } else if (NTW == 6) {
+        if (tw == 0)      tile_wave_loop<T, 2, 3, 0>(hs, cs, pcol, lane);
+        else if (tw == 1) tile_wave_loop<T, 2, 3, 2>(hs, cs, pcol, lane);
+        else if (tw == 2) tile_wave_loop<T, 2, 2, 0>(hs, cs, pcol, lane);
+        else if (tw == 3) tile_wave_loop<T, 2, 2, 2>(hs, cs, pcol, lane);
+        else if (tw == 4) tile_wave_loop<T, 4, 1, 0>(hs, cs, pcol, lane);
+        else              tile_wave_loop<T, 4, 0, 0>(hs, cs, pcol, lane);
+    } else {
+        if (tw == 0)      tile_wave_loop<T, 4, 3, 0>(hs, cs, pcol, lane);
+        else if (tw == 1) tile_wave_loop<T, 4, 2, 0>(hs, cs, pcol, lane);
+        else              tile_wave_loop<T, 4, 1, 0, 4, 0, 0>(hs, cs, pcol, lane);
+    }
+    STAMP(3);
+    __syncthreads();
+    if (tid < 64) diag_roots<T>(cs, rall, lane, w, info, col_base);
+    __syncthreads();
+    for (int e = tid; e < SB * SB; e += NT) {
+        const int r = e >> 6, c = e & 63;
+        if (r < w && c <= r) D[(int64_t)r * ld + c] = cs[r * LS + c] * rall[c];
+        T v = (T)0;
+        if (r < w && c < r) v = cs[c * LS + r] * rall[r] * (rall[c] * rall[c]);      // inverse column c is kept scaled by d_c
+        if (r < w && c == r) v = rall[r];
+        inv[e] = v;
+    }
+    STAMP(4);
+}
+
+// Nine-wave kernels: wave 8 is the pivot wave; it shares SIMD 0 with waves 0 and 4 (waves of a workgroup are
+// dealt to the four SIMDs round-robin: tools/diag_probe.hip prints it), which therefore own nothing in the
+// pivot loop; tile wave numbers 0..5 go to waves 1, 2, 3, 5, 6, 7.
+constexpr int NINE_TW = 6;
+static __device__ __forceinline__ int nine_tile_wave(int g) { return ((g & 3) == 0) ? -1 : (g < 4 ? g - 1 : g - 2); }
+
+// Entry of the nine-wave kernels: the eight tile waves hold S in accumulator layout (wave g: row tile
+// (g >> 1) & 3, column tiles 2 (g & 1) + {0, 1}) from their left-looking products; it goes to `cs` (dead on
+// entry), and behind one barrier -- after which `pcol`, `hs`, `rall` must be dead too -- the pivot loop runs
+// with the roles above.
 template <typename T>
 static __device__ __forceinline__ void diag_tail(typename Mx<T>::acc_t (&acc)[2], T* __restrict__ pcol, T* __restrict__ hs,
                                                   T* __restrict__ cs, T* __restrict__ rall, T* __restrict__ D, int64_t ld,
                                                   int w, T* __restrict__ inv, int32_t* info, int col_base)
 {
     using X = Mx<T>;
-    constexpr int LS = SB + 2;       // even pitch: a row's 4 block columns are one 16-byte-aligned pair of stores
-    constexpr int BC = 4;
-    constexpr int NP = SB / BC;
+    constexpr int LS = SB + 2;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int i = lane;
     const int g = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave id: provably uniform
-    const bool tile_wave = g < DG_TW;
-    const int br = (g >> 1) & 3, ch = g & 1;
-    const int fcol = lane & 15, fk = lane >> 4;
-    // pcol[b][row][t] and hs[b][row][t]: b = double buffer, t = column within the block of 4
-    auto PC = [&](int b, int row, int t) -> T& { return pcol[(b * SB + row) * BC + t]; };
-    auto HS = [&](int b, int row, int t) -> T& { return hs[(b * SB + row) * BC + t]; };
-    if (tile_wave) {
-        // blocks 0 and 1 for the pivot wave (both in tile column 0)
-        if (ch == 0 && fcol < 2 * BC) {
+    if (g < DG_TW) {
+        const int br = (g >> 1) & 3, ch = g & 1;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) PC(fcol / BC, br * 16 + X::crow(lane, r), fcol % BC) = acc[0][r];
-        }
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                cs[(br * 16 + X::crow(lane, r)) * LS + (2 * ch + c) * 16 + (lane & 15)] = acc[c][r];
     }
     lds_barrier();
-    STAMP(2);
-
-    T cv[BC], rr[BC], hsr[BC];                     // pivot wave: this row's block columns, roots, left operand
-#pragma unroll
-    for (int t = 0; t < BC; ++t) { cv[t] = (T)0; rr[t] = (T)1; hsr[t] = (T)0; }
-
-    for (int p = 0; p < NP; ++p) {
-        const int j0 = BC * p, bc0 = j0 >> 4, jb = j0 & 15;
-        if (!tile_wave) {
-            // ---- pivot wave: dependent FP64 ops and nothing else
-            if (p == 8) STAMPW(16, DG_TW);
-            // this row's share of block p as gathered (two 16-byte reads, in flight during the FMAs below)
-            const T* gp = &PC(p & 1, i, 0);
-            T nx[BC];
-#pragma unroll
-            for (int t = 0; t < BC; ++t) nx[t] = gp[t];
-            const int bad = pivot_block<T>(p, nx, cv, rr, hsr, &HS(p & 1, i, 0), cs, rall, i, w);
-            lds_barrier();
-            if (p == 8) STAMPW(20, DG_TW);
-            if (p == 9) STAMPW(21, DG_TW);
-            if (bad != 0 && lane == 0) atomicCAS(info, 0, col_base + bad);
-        } else {
-            if (p == 8) STAMPW(12, 3);
-            lds_barrier();
-            if (p == 8) STAMPW(13, 3);
-            // ---- tile waves: block p's rank-4 update of every tile right of (or containing the
-            // rest of) the block, then the gather of block p+2 (updated through block p)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int bc = 2 * ch + c;
-                if (bc >= bc0) {
-                    const int col = bc * 16 + fcol;
-                    if (br == bc0) {                              // rows of the block: their slots right of it restart from 0
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int rin = X::crow(lane, r);
-                            if (rin >= jb && rin < jb + BC && col >= j0 + BC) acc[c][r] = (T)0;
-                        }
-                    }
-                    const T af = HS(p & 1, br * 16 + fcol, fk);
-                    T bf = cs[(bc * 16 + fcol) * LS + j0 + fk];
-                    if (col < j0 + BC) bf = (T)0;                 // columns of the block and left of it are final
-                    acc[c] = mfma_k4(af, bf, acc[c]);
-                }
-            }
-            if (p + 2 < NP) {
-                const int g0 = j0 + 2 * BC, gbc = g0 >> 4, gjb = g0 & 15;     // block p+2
-                if (ch == (gbc >> 1) && fcol >= gjb && fcol < gjb + BC) {
-                    const int c = gbc & 1;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        PC(p & 1, br * 16 + X::crow(lane, r), fcol - gjb) = (c == 0) ? acc[0][r] : acc[1][r];
-                }
-            }
-            if (p == 8) STAMPW(14, 3);
-        }
-    }
-    STAMP(3);
-    __syncthreads();
-    for (int e = tid; e < SB * SB; e += DG_NT) {
-        const int r = e >> 6, c = e & 63;
-        if (r < w && c <= r) D[(int64_t)r * ld + c] = cs[r * LS + c] * rall[c];
-        T v = (T)0;
-        if (r < w && c < r) v = cs[c * LS + r] * rall[r];
-        if (r < w && c == r) v = rall[r];
-        inv[e] = v;
-    }
-    STAMP(4);
+    diag_tail_lds<T, NINE_TW, DG_NT>(nine_tile_wave(g), g == DG_TW, pcol, hs, cs, rall, D, ld, w, inv, info, col_base);
 }
 
 // LDS of the factorisation proper, in bytes: pivot columns (cs), gathered columns and left operand
@@ -922,8 +1083,8 @@ void k_link(T* __restrict__ A, int64_t ld, int n, int c0, int k0, int wn,
     }
     constexpr int TT = 64 * DG_TW;                   // threads of the tile waves
     constexpr int NR = SB * TL::CPR / TT;            // 16-byte pieces per thread and 64 x 64 tile
-    static_assert(SB * TL::LROW >= DiagLds<T>::CS, "pivot columns overlay the first operand tile");
-    static_assert(SB * TL::LROW >= 2 * DiagLds<T>::PCOL + DiagLds<T>::RALL, "gather buffers overlay the second operand tile");
+    static_assert(SB * TL::LROW >= DiagLds<T>::CS, "pivot columns overlay the second operand tile");
+    static_assert(SB * TL::LROW >= 2 * DiagLds<T>::PCOL + DiagLds<T>::RALL, "gather buffers overlay the first operand tile");
     unsigned char* bufA = smem;                      // own rows' chunk (both operands of S, left operand of T), then T, then X
     unsigned char* bufB = smem + SB * TL::LROW;      // Lrow chunk, then inv(L_ss)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1041,12 +1202,12 @@ void k_link(T* __restrict__ A, int64_t ld, int n, int c0, int k0, int wn,
                 acc[c][r] = v;
             }
     }
-    // The second tile is dead since the barrier above (gather buffers go there); the first is read
-    // by the last multiply until diag_tail's first barrier, after which the pivot columns overlay it.
-    T* pcol = reinterpret_cast<T*>(bufB);
-    T* hs   = reinterpret_cast<T*>(bufB + DiagLds<T>::PCOL);
-    T* rall = reinterpret_cast<T*>(bufB + 2 * DiagLds<T>::PCOL);
-    diag_tail<T>(acc, pcol, hs, reinterpret_cast<T*>(bufA), rall, D, ld, wn,
+    // The second tile is dead since the barrier above: S goes there (diag_tail) and becomes the pivot columns;
+    // the first is read by the last multiply until diag_tail's barrier and then holds the gather buffers.
+    T* pcol = reinterpret_cast<T*>(bufA);
+    T* hs   = reinterpret_cast<T*>(bufA + DiagLds<T>::PCOL);
+    T* rall = reinterpret_cast<T*>(bufA + 2 * DiagLds<T>::PCOL);
+    diag_tail<T>(acc, pcol, hs, reinterpret_cast<T*>(bufB), rall, D, ld, wn,
                  ws + (int64_t)(r0 / SB) * (SB * SB), info, r0);
 }
 
@@ -1065,104 +1226,6 @@ void k_link(T* __restrict__ A, int64_t ld, int n, int c0, int k0, int wn,
 // ---------------------------------------------------------------------------
 constexpr int Q_TW = 3;               // tile waves
 constexpr int Q_NT = 256;             // threads
-constexpr int Q_TILES = 6;            // most tiles one wave owns
-
-template <typename T>
-static __device__ __forceinline__ void diag_tail4(T* __restrict__ pcol, T* __restrict__ hs, T* __restrict__ cs,
-                                                   T* __restrict__ rall, T* __restrict__ D, int64_t ld,
-                                                   int w, T* __restrict__ inv, int32_t* info, int col_base)
-{
-    using X = Mx<T>;
-    using acc_t = typename X::acc_t;
-    constexpr int LS = SB + 2;
-    constexpr int BC = 4;
-    constexpr int NP = SB / BC;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int i = lane;
-    const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool tile_wave = g < Q_TW;
-    const int fcol = lane & 15, fk = lane >> 4;
-    auto PC = [&](int b, int row, int t) -> T& { return pcol[(b * SB + row) * BC + t]; };
-    auto HS = [&](int b, int row, int t) -> T& { return hs[(b * SB + row) * BC + t]; };
-    // on entry `cs` holds the Schur complement S (lower), identity padding beyond w, zeros above
-    acc_t acc[Q_TILES];
-#pragma unroll
-    for (int k = 0; k < Q_TILES; ++k) {
-        acc[k] = acc_zero<T>();
-        const int t = g + Q_TW * k;
-        if (tile_wave && t < 16) {
-            const int br = t >> 2, bc = t & 3;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[k][r] = cs[(br * 16 + X::crow(lane, r)) * LS + bc * 16 + fcol];
-        }
-    }
-    T cv[BC], rr[BC], hsr[BC];
-#pragma unroll
-    for (int t = 0; t < BC; ++t) { cv[t] = (T)0; rr[t] = (T)1; hsr[t] = (T)0; }
-    T first[2][BC];                                  // pivot wave: blocks 0 and 1 straight from S
-    if (!tile_wave) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int t = 0; t < BC; ++t) first[b][t] = cs[i * LS + b * BC + t];
-    }
-    lds_barrier();                                   // every wave has taken its share of S: cs may be overwritten
-
-    for (int p = 0; p < NP; ++p) {
-        const int j0 = BC * p, bc0 = j0 >> 4, jb = j0 & 15;
-        if (!tile_wave) {
-            T nx[BC];
-            if (p < 2) {
-#pragma unroll
-                for (int t = 0; t < BC; ++t) nx[t] = (p == 0) ? first[0][t] : first[1][t];
-            } else {
-                const T* gp = &PC(p & 1, i, 0);
-#pragma unroll
-                for (int t = 0; t < BC; ++t) nx[t] = gp[t];
-            }
-            const int bad = pivot_block<T>(p, nx, cv, rr, hsr, &HS(p & 1, i, 0), cs, rall, i, w);
-            lds_barrier();
-            if (bad != 0 && lane == 0) atomicCAS(info, 0, col_base + bad);
-        } else {
-            lds_barrier();
-            const int g0 = j0 + 2 * BC, gbc = g0 >> 4, gjb = g0 & 15;         // block p+2, gathered below
-#pragma unroll
-            for (int k = 0; k < Q_TILES; ++k) {
-                const int t = g + Q_TW * k;
-                if (t < 16) {
-                    const int br = t >> 2, bc = t & 3;
-                    if (bc >= bc0) {
-                        const int col = bc * 16 + fcol;
-                        if (br == bc0) {                          // rows of the block: their slots right of it restart from 0
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int rin = X::crow(lane, r);
-                                if (rin >= jb && rin < jb + BC && col >= j0 + BC) acc[k][r] = (T)0;
-                            }
-                        }
-                        const T af = HS(p & 1, br * 16 + fcol, fk);
-                        T bf = cs[(bc * 16 + fcol) * LS + j0 + fk];
-                        if (col < j0 + BC) bf = (T)0;             // columns of the block and left of it are final
-                        acc[k] = mfma_k4(af, bf, acc[k]);
-                    }
-                    if (p + 2 < NP && bc == gbc && fcol >= gjb && fcol < gjb + BC) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) PC(p & 1, br * 16 + X::crow(lane, r), fcol - gjb) = acc[k][r];
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    for (int e = tid; e < SB * SB; e += Q_NT) {
-        const int r = e >> 6, c = e & 63;
-        if (r < w && c <= r) D[(int64_t)r * ld + c] = cs[r * LS + c] * rall[c];
-        T v = (T)0;
-        if (r < w && c < r) v = cs[c * LS + r] * rall[r];
-        if (r < w && c == r) v = rall[r];
-        inv[e] = v;
-    }
-}
 
 // Schur complement from row-tile accumulators to `cs` (identity padding beyond w, zeros above the diagonal)
 template <typename T>
@@ -1250,8 +1313,8 @@ void k_diag64q(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow,
     }
     schur_to_lds<T>(reinterpret_cast<T*>(cs_), dval, pacc, wave, lane, w);
     __syncthreads();
-    diag_tail4<T>(reinterpret_cast<T*>(pcol_), reinterpret_cast<T*>(hs_), reinterpret_cast<T*>(cs_),
-                  reinterpret_cast<T*>(rall_), D, ld, w, inv, info, col_base);
+    diag_tail_lds<T, Q_TW, Q_NT>(wave < Q_TW ? wave : -1, wave == Q_TW, reinterpret_cast<T*>(pcol_), reinterpret_cast<T*>(hs_),
+                                 reinterpret_cast<T*>(cs_), reinterpret_cast<T*>(rall_), D, ld, w, inv, info, col_base);
 }
 
 // k_link with four-wave workgroups throughout (see k_link for what a link does).
@@ -1415,8 +1478,8 @@ void k_linkq(T* __restrict__ A, int64_t ld, int n, int c0, int k0, int wn,
     T* pcol = reinterpret_cast<T*>(bufA);
     T* hs   = reinterpret_cast<T*>(bufA + DiagLds<T>::PCOL);
     T* rall = reinterpret_cast<T*>(bufA + 2 * DiagLds<T>::PCOL);
-    diag_tail4<T>(pcol, hs, reinterpret_cast<T*>(bufB), rall, D, ld, wn,
-                  ws + (int64_t)(r0 / SB) * (SB * SB), info, r0);
+    diag_tail_lds<T, Q_TW, Q_NT>(wave < Q_TW ? wave : -1, wave == Q_TW, pcol, hs, reinterpret_cast<T*>(bufB), rall, D, ld, wn,
+                                 ws + (int64_t)(r0 / SB) * (SB * SB), info, r0);
 }
 
 // All four sub-steps of a panel for rows that take no part in the factorisation itself (the
@@ -1484,15 +1547,20 @@ void k_invT_panel(T* __restrict__ invT, const T* __restrict__ L, int64_t ld, int
 // count of stored head tiles (k_gemm_nt_pers adds 1 per tile behind an agent-scope release) and ends; the
 // chain's next launch follows it in queue order.  One resident wave cannot starve the update of compute
 // units (a poll inside the wide panel-solve launch could: its hundreds of workgroups would hold the units the
-// persistent workgroups are waiting for).  The poll is bounded (~seconds): on expiry the factorisation is
-// flagged as failed (info = INT_MAX) instead of hanging the device.
+// persistent workgroups are waiting for).  The poll is bounded by the constant 100 MHz clock (s_memrealtime):
+// after GATE_TIMEOUT_TICKS = 2 s without the count the factorisation is flagged with CIMRGP_INFO_WATCHDOG
+// (include/cimrgp.h: a SCHEDULE failure, not a numerical one) instead of hanging the device.
+constexpr long long GATE_TIMEOUT_TICKS = 200000000ll;
 __global__ void k_gate(const int* __restrict__ flag, int expected, int32_t* info)
 {
     if (threadIdx.x == 0) {
-        int spins = 0;
+        const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
             __builtin_amdgcn_s_sleep(64);
-            if (++spins > (1 << 24)) { atomicCAS(info, 0, 0x7fffffff); break; }
+            if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > GATE_TIMEOUT_TICKS) {
+                atomicCAS(info, 0, CIMRGP_INFO_WATCHDOG);
+                break;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
@@ -2089,17 +2157,27 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     // Host threads whose streams share a context serialise their ENQUEUE (microseconds); distinct
     // caller streams have distinct contexts and enqueue concurrently.
     std::lock_guard<std::mutex> guard(la->enqueue);
-    if (!grow_events(la, (size_t)(9 * npanels + 16))) return fail("cimrgp_potrf", "hipEventCreate failed");
+    if (!grow_events(la, (size_t)(9 * npanels + 16 + 4))) return fail("cimrgp_potrf", "hipEventCreate failed");
     hipStream_t sp = la->side;
     hipStream_t sb = la->bulk ? la->bulk : st;         // bulk trailing updates
     size_t ne = 0;
+    // The device counter of the gate belongs to the CONTEXT, and beyond MAX_CTX contexts a context serves caller
+    // streams other than its owner (acquire_ctx, by hash).  Only the owner's factorisations may reset and count on
+    // it: a second caller stream would reset the counter under the owner's in-flight gates (which then expire) and
+    // have its own gates satisfied by the owner's tiles (a silently wrong factor).  Everybody else keeps the head
+    // update on the chain queue (round 2's schedule), which needs no counter.
+    const bool may_gate = la->gate_ok && la->owner == st;
+    // Everything below enqueues on several queues; an error return in the middle must not leave the caller's
+    // stream running ahead of work already queued on them (the caller may free or reuse K / workspace / B):
+    // the enqueue proper is `body`, and whatever it returns the queues are joined into `st` behind it.
+    auto body = [&]() -> int {
     // The side stream runs the whole latency-bound chain in stream order -- "head" update of the
     // next panel's columns, then that panel's factorisation -- so that no inter-queue signal
     // sits between two links of the chain; the caller's stream runs the bulk of each trailing
     // update (and, off the chain, the carried rows).  Cross-stream edges: "panel final"
     // (side -> main, before the bulk update that reads it) and "bulk update done" (main -> side,
     // before the next head touches columns the bulk update wrote).
-    CIMRGP_HIP_TRY(hipMemsetAsync(la->flag, 0, sizeof(int), st), "hipMemsetAsync(flag)");
+    if (may_gate) CIMRGP_HIP_TRY(hipMemsetAsync(la->flag, 0, sizeof(int), st), "hipMemsetAsync(flag)");
     int flag_expected = 0;                             // head tiles the chain has been told to wait for so far
     hipEvent_t ev_start = la->ev[ne++];
     CIMRGP_HIP_TRY(hipEventRecord(ev_start, st), "hipEventRecord");
@@ -2285,7 +2363,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
         // (not while the carried rows are running: their kernels hold compute units the persistent workgroups
         // of the combined launch -- head tiles included -- would have to wait for: 114 -> 109 posteriors/s)
         const bool rows_running = rows && !rows_fused && (n - k1 <= knobs().rows_start_below);
-        const int heads = (la->gate_ok && knobs().chain_mode == 0 && !rows_running && w == CIMRGP_NB && wn == CIMRGP_NB && n > k2 && !grp_open() &&
+        const int heads = (may_gate && knobs().chain_mode == 0 && !rows_running && w == CIMRGP_NB && wn == CIMRGP_NB && n > k2 && !grp_open() &&
                            group_size(n - k2 - ((n - k2 < CIMRGP_NB) ? (n - k2) : CIMRGP_NB), knobs().far_pair_above) == 1)
                               ? gemm_pers_head_tiles(n - k1, (int)w, (int)sizeof(T)) : 0;
         if (heads > 0) {
@@ -2442,6 +2520,19 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
         if (sb != st && ev_bulk_last) CIMRGP_HIP_TRY(hipStreamWaitEvent(st, ev_bulk_last, 0), "hipStreamWaitEvent");
     }
     return build_invT<T>(k, n, ld, ws, st);
+    };   // body
+    const int rc_body = body();
+    if (rc_body != 0) {
+        // failed enqueue: the caller's stream waits for everything that did get queued (errors of the join itself
+        // cannot improve on the one being reported)
+        size_t je = la->ev.size() - 4;
+        for (hipStream_t q : {la->side, la->bulk, la->rows, la->rows_far}) {
+            if (q == nullptr) continue;
+            hipEvent_t ev = la->ev[je++];
+            if (hipEventRecord(ev, q) == hipSuccess) (void)hipStreamWaitEvent(st, ev, 0);
+        }
+    }
+    return rc_body;
 }
 
 // `bt.count` equal-sized factorisations (the blocks of one layer) in the SAME launches: every

@@ -205,10 +205,23 @@ def solve_lt(lbuf, n, ws, z):
     return z
 
 
+#: include/cimrgp.h CIMRGP_INFO_WATCHDOG: the factorisation's schedule failed, not the matrix
+INFO_WATCHDOG = 0x7fffffff
+
+
+def is_watchdog(code):
+    """``code``: an ``info`` word, possibly after a trip through a floating-point collective (float32 rounds
+    2^31 - 1 up to 2^31; sums over ranks only grow)."""
+    return float(code) >= float(INFO_WATCHDOG) - 128.0
+
+
 def raise_if_not_pd(info):
-    """LinAlgError is the exception the reference's PD guard keys on
-    (SanityCheck.py:59-65)."""
+    """LinAlgError is the exception the reference's PD guard keys on (SanityCheck.py:59-65); a schedule
+    watchdog (CIMRGP_INFO_WATCHDOG) is NOT a numerical failure and must not be repaired as one: RuntimeError."""
     code = int(info.item()) if isinstance(info, torch.Tensor) else int(info)
+    if is_watchdog(code):
+        raise RuntimeError("cimrgp_potrf: schedule watchdog (a device-side wait inside the factorisation expired; "
+                           "the result is undefined and the matrix was not judged)")
     if code != 0:
         raise np.linalg.LinAlgError("Matrix is not positive definite (leading minor of order %d)" % code)
 

@@ -36,6 +36,14 @@ extern "C" {
 
 enum { CIMRGP_F32 = 0, CIMRGP_F64 = 1 };
 
+/* *info_dev values other than LAPACK's: CIMRGP_INFO_WATCHDOG = the factorisation's internal schedule
+ * gave up waiting for one of its own kernels (a bounded device-side wait of 2 s expired: the panel chain
+ * waits for tiles of the trailing update through a device counter).  It says nothing about the matrix;
+ * the result is undefined.  The Python wrapper raises RuntimeError("schedule watchdog"), NOT the
+ * numpy.linalg.LinAlgError that the reference's positive-definiteness guard catches and repairs
+ * (src/SanityCheck.py:59-65).  No leading minor can have this order (n < 2^30 is enforced). */
+#define CIMRGP_INFO_WATCHDOG 0x7fffffff
+
 /* Outer block size of the factorisation (columns per panel).  The workspace
  * keeps ceil(n/64) inverted 64x64 diagonal blocks followed by ceil(n/256)
  * blocks (L_pp^-1)^T of CIMRGP_NB x CIMRGP_NB. */

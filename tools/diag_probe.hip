@@ -1,7 +1,9 @@
 // Diagnostic: phase stamps (s_memtime: shader clocks, ~2.35 GHz under load) of the diagonal kernel and
 // whole one-queue factorisations per chain form.
 // Not part of the product.   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/diag_probe.hip -o tools/diag_probe
+#ifndef NOSTAMP
 #define CIMRGP_STAMP 1
+#endif
 #include "../cimrgp_amd/csrc/potrf.hip"
 #include "../cimrgp_amd/csrc/gemm_nt.hip"
 #include <cmath>
@@ -12,6 +14,15 @@ static std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
 int fail(const char* fn, const char* what) { fprintf(stderr, "%s: %s\n", fn, what); return -1; }
 int check_hip(hipError_t e, const char* fn, const char* what) { fprintf(stderr, "%s: %s: %s\n", fn, what, hipGetErrorString(e)); return -2; }
+const Knobs& knobs() { static Knobs k; return k; }
+int rows_queues() { return 2; }
+}
+
+// which SIMD each wave of a workgroup lands on (HW_REG_HW_ID: SIMD_ID = bits 5:4)
+__global__ void k_simd_ids(int* out)
+{
+    const int hw = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);      // 16 bits of HW_ID
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * 16 + (threadIdx.x >> 6)] = hw;
 }
 
 static double tick_us(long long t) { return t / 2350.0; }     // shader clocks at ~2.35 GHz
@@ -31,14 +42,87 @@ int main()
     // one stamped diagonal kernel (first sub-block of a panel): where its 17 us go
     for (int rep = 0; rep < 2; ++rep) {
         hipMemcpy(dK, h.data(), h.size() * 8, hipMemcpyHostToDevice); hipMemset(dinfo, 0, 4);
-        hipLaunchKernelGGL((k_diag64<double>), dim3(1), dim3(DG_NT), 0, 0, dK, (int64_t)ld, 64, dK, 0, dws, dinfo, 0);
+        hipLaunchKernelGGL((k_diag64<double>), dim3(1), dim3(DG_NT), 0, 0, dK, (int64_t)ld, 64, (const double*)dK, 0, dws, dinfo, 0, (int64_t)0, (int64_t)0, (int64_t)0, no_riders<double>());
         hipDeviceSynchronize();
+#ifdef CIMRGP_STAMP
         hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamp), sizeof(st));
+#else
+        for (auto& v : st) v = 0;
+#endif
         if (rep)
             printf("k_diag64 (nine waves): load+gather %.2f us, pivot loop %.2f us, store %.2f us | pivot wave, block 8: read+self-update %.0f, "
                    "4 pivots %.0f, publish %.0f, barrier %.0f clocks; next block starts %.0f after this one; tile wave 3: wait %.0f, update+gather %.0f\n",
                    tick_us(st[2] - st[0]), tick_us(st[3] - st[2]), tick_us(st[4] - st[3]), (double)(st[17] - st[16]), (double)(st[18] - st[17]),
                    (double)(st[19] - st[18]), (double)(st[20] - st[19]), (double)(st[21] - st[16]), (double)(st[13] - st[12]), (double)(st[14] - st[13]));
+        if (rep)
+            printf("raw stamps relative to pivot-wave iteration start (16): tile wave 3 arrives at barrier %lld, leaves %lld, done update+gather %lld; "
+                   "pivot wave: selfupd done %lld, pivots done %lld, published %lld, past barrier %lld, next iteration past barrier %lld\n",
+                   st[12] - st[16], st[13] - st[16], st[14] - st[16], st[17] - st[16], st[18] - st[16], st[19] - st[16], st[20] - st[16], st[21] - st[16]);
+    }
+    {
+        int* dsimd; hipMalloc(&dsimd, 4 * 16 * 4);
+        int hs[64];
+        for (int nt : {576, 256, 768}) {
+            hipMemset(dsimd, 0xff, 4 * 16 * 4);
+            hipLaunchKernelGGL(k_simd_ids, dim3(4), dim3(nt), 0, 0, dsimd);
+            hipMemcpy(hs, dsimd, sizeof(hs), hipMemcpyDeviceToHost);
+            for (int b = 0; b < 4; ++b) {
+                printf("workgroup %d of %d threads: simd of waves:", b, nt);
+                for (int wv = 0; wv < nt / 64; ++wv) printf(" %d", (hs[b * 16 + wv] >> 4) & 3);
+                printf("  (cu %d)\n", (hs[b * 16] >> 8) & 15);
+            }
+        }
+    }
+    // the two forms of the diagonal kernel must agree (L in place, inverse in the workspace)
+    for (int kprev : {0, 192}) {
+        std::vector<double> out[2], inv[2];
+        for (int form = 0; form < 2; ++form) {
+            hipMemcpy(dK, h.data(), h.size() * 8, hipMemcpyHostToDevice); hipMemset(dinfo, 0, 4);
+            double* blk = dK + (size_t)256 * ld + 256;                 // a block with 256 columns to its left
+            const double* lrow = blk - kprev;
+            if (form == 0) hipLaunchKernelGGL((k_diag64<double>), dim3(1), dim3(DG_NT), 0, 0, blk, (int64_t)ld, 64, lrow, kprev, dws, dinfo, 0, (int64_t)0, (int64_t)0, (int64_t)0, no_riders<double>());
+            else hipLaunchKernelGGL((k_diag64q<double>), dim3(1), dim3(Q_NT), 0, 0, blk, (int64_t)ld, 64, lrow, kprev, dws, dinfo, 0, (int64_t)0, (int64_t)0, (int64_t)0, no_riders<double>());
+            hipDeviceSynchronize();
+            out[form].resize(64 * 64); inv[form].resize(64 * 64);
+            for (int r = 0; r < 64; ++r) hipMemcpy(&out[form][r * 64], blk + (size_t)r * ld, 64 * 8, hipMemcpyDeviceToHost);
+            hipMemcpy(inv[form].data(), dws, 64 * 64 * 8, hipMemcpyDeviceToHost);
+            int32_t info; hipMemcpy(&info, dinfo, 4, hipMemcpyDeviceToHost);
+            printf("kprev %d form %d info %d L[0][0] %.6f L[63][63] %.6f inv[63][0] %.6e\n", kprev, form, info, out[form][0], out[form][63 * 64 + 63], inv[form][63 * 64]);
+        }
+        double dl = 0, di = 0;
+        for (int r = 0; r < 64; ++r) for (int c = 0; c <= r; ++c) {
+            dl = std::max(dl, std::fabs(out[0][r * 64 + c] - out[1][r * 64 + c]));
+            di = std::max(di, std::fabs(inv[0][r * 64 + c] - inv[1][r * 64 + c]));
+        }
+        printf("kprev %d: nine-wave vs four-wave max |dL| %.3e max |dinv| %.3e\n", kprev, dl, di);
+        if (kprev == 0) {
+            // which 4-column blocks of L differ, per 16-row tile (X = differs)
+            for (int rt = 0; rt < 4; ++rt) {
+                printf("rows %2d-%2d:", rt * 16, rt * 16 + 15);
+                for (int cb = 0; cb < 16; ++cb) {
+                    double m = 0;
+                    for (int r = rt * 16; r < rt * 16 + 16; ++r) for (int c = cb * 4; c < cb * 4 + 4; ++c)
+                        if (c <= r) m = std::max(m, std::fabs(out[0][r * 64 + c] - out[1][r * 64 + c]));
+                    printf(" %c", m > 1e-9 ? 'X' : '.');
+                }
+                printf("\n");
+            }
+            for (int r = 16; r < 26; ++r) printf("row %d col 20: nine %.6f four %.6f | col 16: %.6f %.6f\n", r, out[0][r * 64 + 20], out[1][r * 64 + 20], out[0][r * 64 + 16], out[1][r * 64 + 16]);
+        }
+    }
+    // un-stamped rate: 200 back-to-back launches of each diagonal kernel on a 64 x 64 block (kprev = 0)
+    for (int form = 0; form < 2; ++form) {
+        for (int rep = 0; rep < 2; ++rep) {
+            hipMemcpy(dK, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+            hipEventRecord(e0);
+            for (int it = 0; it < 200; ++it) {
+                if (form == 0) hipLaunchKernelGGL((k_diag64<double>), dim3(1), dim3(DG_NT), 0, 0, dK + (size_t)(it % 32) * 64 * (ld + 1), (int64_t)ld, 64, (const double*)dK, 0, dws, dinfo, 0, (int64_t)0, (int64_t)0, (int64_t)0, no_riders<double>());
+                else hipLaunchKernelGGL((k_diag64q<double>), dim3(1), dim3(Q_NT), 0, 0, dK + (size_t)(it % 32) * 64 * (ld + 1), (int64_t)ld, 64, (const double*)dK, 0, dws, dinfo, 0, (int64_t)0, (int64_t)0, (int64_t)0, no_riders<double>());
+            }
+            hipEventRecord(e1); hipDeviceSynchronize();
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            if (rep) printf("%s: %.2f us per launch (200 back to back)\n", form == 0 ? "k_diag64 " : "k_diag64q", ms * 1000.0 / 200);
+        }
     }
     // the chain of one panel, alone on the machine, in its three forms (whole factorisations of n = 4096, one queue)
     // (the form is read once per process: CIMRGP_CHAIN=split|wide|quad tools/diag_probe)
