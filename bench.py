@@ -336,46 +336,56 @@ def main():
     yd = dev.to_device(y, tdt, device)
     xsd = dev.to_device(workloads.block_test_points(ns), tdt, device)
 
-    # buffers allocated once: the step itself never allocates the big matrices
+    # Buffers allocated once.  The timed step is ONE call of the boundary's fused entry point,
+    # cimrgp_block_posterior (include/cimrgp.h: Gram, cross-Gram and target rows, factorisation with the rows
+    # carried, backward solve, mean and variance), on these buffers: no torch kernel and no allocation inside it.
+    # Its outputs land directly in this rank's slices of the fused [mean (ns_total x q) | var (ns_total)] buffer of
+    # the step's one collective.
     kbuf = dev.alloc_matrix(n, n, tdt, device)
     wbuf = dev.alloc_matrix(ns + q, n, tdt, device)      # carried rows: [K(X*, X); r^T]
     ws = dev.potrf_workspace(n, tdt, device)
     info = torch.zeros(1, dtype=torch.int32, device=device)
-    fused = torch.zeros((q + 1, ns * world), dtype=tdt, device=device)
-    mean = torch.zeros((ns, q), dtype=tdt, device=device)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
-    stage_ms = np.zeros(5)
+    nst = ns * world
+    fused = torch.zeros(nst * (q + 1), dtype=tdt, device=device)
+    mean = fused[:nst * q].view(nst, q)[rank * ns:(rank + 1) * ns]          # (ns x q), contiguous
+    var = fused[nst * q:][rank * ns:(rank + 1) * ns]                        # (ns,)
+    alpha = torch.empty((n, q), dtype=tdt, device=device)
+    zbuf = torch.empty((n, q), dtype=tdt, device=device)
+    scratch = torch.empty(2 * q * n, dtype=tdt, device=device)
+    others = [fused[:nst * q].view(nst, q)[:rank * ns], fused[:nst * q].view(nst, q)[(rank + 1) * ns:],
+              fused[nst * q:][:rank * ns], fused[nst * q:][(rank + 1) * ns:]] if world > 1 else []
 
-    def step(timed):
-        if timed:
-            ev[0].record()
-        dev.rbf_gram(xd, ell, sf2, noise, lower_only=True, out=kbuf)               # D1
-        if timed:
-            ev[1].record()
-        dev.rbf_cross(xsd, xd, ell, sf2, out=wbuf)                                  # rows of D5 ...
-        wbuf[ns:ns + q, :n] = yd.t()                                                # ... and of D3's forward half
-        if timed:
-            ev[2].record()
-        # D2 with the rows carried through the same panel sweep: W = K* L^-T and z^T = (L^-1 r)^T
-        dev.potrf_rows(kbuf, n, wbuf, ns + q, ws, info)
-        if timed:
-            ev[3].record()
-        z = wbuf[ns:ns + q, :n].t().contiguous()
-        alpha = dev.solve_lt(kbuf, n, ws, z.clone())                                # D3 backward half
-        # the previous step's collective owns `fused` until it is done: the stream waits for it HERE, a whole
-        # factorisation after it was started, so its latency never shows (the host does not block)
+    def step(wait_inside=False):
+        # the previous step's collective owns `fused` until it is done: the STREAM waits for it here (the host does
+        # not block), a whole step after it was started
         if pending[0] is not None:
             pending[0].wait()
             pending[0] = None
-        fused.zero_()                                                               # the other ranks' slices
-        var = fused[q, rank * ns:(rank + 1) * ns]
-        dev.predict_from_w(wbuf, ns, n, z, sf2, 0.0, None, mean, var, accumulate=False)   # D4 + D5 tail
-        if timed:
-            ev[4].record()
-        fused[:q, rank * ns:(rank + 1) * ns] = mean.t()
+        for t in others:                                                        # the other ranks' slices (world > 1 only)
+            t.zero_()
+        dev.block_posterior(xd, yd, xsd, ell, sf2, noise, kbuf, wbuf, ws, info, alpha, zbuf, mean, var, scratch=scratch)
         pending[0] = dist.allreduce_sum_begin(fused, force=args.nccl_world1)        # the one collective
-        if timed:
-            ev[5].record()
+        if wait_inside and pending[0] is not None:
+            pending[0].wait()
+            pending[0] = None
+
+    # the same work as five separate calls (the boundary's fine-grained entry points), with an event between the
+    # stages: run AFTER the timed region, for `stage_ms` only (tests/ hold the two forms to bit-equality)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+
+    def step_in_stages():
+        ev[0].record()
+        dev.rbf_gram(xd, ell, sf2, noise, lower_only=True, out=kbuf)               # D1
+        ev[1].record()
+        dev.rbf_cross(xsd, xd, ell, sf2, out=wbuf)                                  # rows of D5 ...
+        wbuf[ns:ns + q, :n] = yd.t()                                                # ... and of D3's forward half
+        ev[2].record()
+        dev.potrf_rows(kbuf, n, wbuf, ns + q, ws, info)                             # D2 with the rows carried
+        ev[3].record()
+        z = wbuf[ns:ns + q, :n].t().contiguous()
+        dev.solve_lt(kbuf, n, ws, z.clone())                                        # D3 backward half
+        dev.predict_from_w(wbuf, ns, n, z, sf2, 0.0, None, mean, var, accumulate=False)   # D4 + D5 tail
+        ev[4].record()
 
     pending = [None]
 
@@ -390,7 +400,7 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step(False)
+        step()
     drain()
     barrier()
     assert int(info.item()) == 0, "Cholesky failed in warm-up"
@@ -402,7 +412,7 @@ def main():
     for i in range(args.steps):
         if not args.no_launch_events and i % EVENT_EVERY == 0:
             _lib.check(lib.cimrgp_profile_begin(), "cimrgp_profile_begin")
-        step(True)
+        step()
         if i % EVENT_EVERY == 0:
             _lib.check(lib.cimrgp_profile_pause(), "cimrgp_profile_pause")
         # stage times are read after the loop from the last step's events only
@@ -412,12 +422,32 @@ def main():
     tr_ms, tr_fl, tr_by, tr_cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
     _lib.check(lib.cimrgp_profile_collect_bytes(ctypes.byref(tr_ms), ctypes.byref(tr_fl), ctypes.byref(tr_by), ctypes.byref(tr_cnt)),
                "cimrgp_profile_collect_bytes")
-    for i in range(5):
-        stage_ms[i] = ev[i].elapsed_time(ev[i + 1])
-    # the reduced buffer holds this rank's slice unchanged (the other ranks contribute zeros there): exact
-    reduce_diff = float((fused[:q, rank * ns:(rank + 1) * ns] - mean.t()).abs().max().item())
     last_mean = mean.double().cpu().numpy()                    # the last timed step's outputs (this rank)
-    last_var = fused[q, rank * ns:(rank + 1) * ns].double().cpu().numpy()
+    last_var = var.double().cpu().numpy()
+    # the collective of the timed steps is started at the end of a step and waited for (by the stream) at the start
+    # of the next: its latency is hidden.  What it costs when it is NOT hidden: steps that wait for it inside.
+    drained_ms = None
+    if world > 1 or args.nccl_world1:
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            step(wait_inside=True)
+        barrier()
+        drained_ms = (time.perf_counter() - t1) / 5 * 1e3
+    # the reduced buffer holds this rank's slice unchanged (the other ranks contribute zeros there): exact
+    step()
+    mine = torch.cat([mean.reshape(-1), var]).clone()
+    drain()
+    torch.cuda.synchronize()
+    reduce_diff = float((torch.cat([mean.reshape(-1), var]) - mine).abs().max().item())
+    # stage times: the five-call form, outside the timed region (median of 3 after a warm-up)
+    stage_runs = []
+    for rep in range(4):
+        step_in_stages()
+        torch.cuda.synchronize()
+        if rep:
+            stage_runs.append([ev[i].elapsed_time(ev[i + 1]) for i in range(4)])
+    stage_ms = np.median(np.asarray(stage_runs), axis=0)
     # Cholesky alone (no carried rows) for the effective-GFLOP/s figure, timed separately
     torch.cuda.synchronize()
     chol_ms = []
@@ -460,15 +490,20 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 1-D, N=%d single-resolution single-partition RBF GP "
                                    "per GPU, q=2 outputs, N/4=%d test points, ell=0.1, sf2=1, noise=0.01" % (n, ns),
-                       "partitions_per_gpu": 1, "parallelism": "independent partitions, 1 all-reduce/step",
+                       "partitions_per_gpu": 1,
+                       "parallelism": "independent partitions, 1 all-reduce/step (started at the end of a step, waited for by the stream at the start of the next)",
                        "backend": (rehearsal or "nccl") if td.is_initialized() else "none",
                        "rows_queues": int(lib.cimrgp_get_rows_queues())},
             "reduce_selfcheck_max_abs_diff": reduce_diff,
             "cholesky_gflops": chol_gflops,
             "cholesky_frac_of_peak": chol_gflops / 1e3 / peak,
-            "stage_ms": {"gram": stage_ms[0], "cross_gram_and_rhs_rows": stage_ms[1],
-                         "potrf_with_carried_rows": stage_ms[2], "backward_solve_and_predict": stage_ms[3],
-                         "reduce": stage_ms[4], "potrf_alone": chol_ms},
+            "step_is": "ONE cimrgp_block_posterior call per step on preallocated buffers (+ the collective's enqueue)",
+            "reduce_overlapped": bool(world > 1 or args.nccl_world1),
+            "drained_step_ms": drained_ms,
+            "stage_ms": {"measured": "the same work as five separate calls, after the timed region (median of 3)",
+                         "gram": float(stage_ms[0]), "cross_gram_and_rhs_rows": float(stage_ms[1]),
+                         "potrf_with_carried_rows": float(stage_ms[2]), "backward_solve_and_predict": float(stage_ms[3]),
+                         "potrf_alone": chol_ms},
             "gram_gbps_lower": (n * (n + 1) / 2 * (8 if args.dtype == "f64" else 4)) / (stage_ms[0] * 1e-3) / 1e9,
             "roofline": {"bound": "mfma", "kernel": "lower trailing updates of cimrgp_potrf: k_gemm_nt_pers<%s, lower> (look-ahead phase: head + bulk in "
                                                     "one persistent launch) and k_gemm_nt_sub<%s, lower, *>"

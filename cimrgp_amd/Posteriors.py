@@ -177,6 +177,14 @@ def _layer_array(views, group):
     return torch.as_strided(v0, (int(rows), int(v0.shape[1])), v0.stride(), 0)
 
 
+def _same_rows(arrays, group):
+    """Whether region l starts at the same row (counted from the start of the storage) in every one of ``arrays``
+    (lists of region views), for every l of ``group``: a view of y at a non-zero storage offset, say, does not."""
+    def row_of(v):
+        return v.storage_offset() // max(1, v.stride(0))
+    return all(row_of(a[l]) == row_of(arrays[0][l]) for a in arrays[1:] for l in group)
+
+
 class _FittedBatch(object):
     """Equal-sized blocks fitted together: their factors share one arena, so that a prediction can
     address block i at ``base + i * stride`` (cimrgp_layer_predict)."""
@@ -224,7 +232,10 @@ class DensePosterior(object):
             by_size.setdefault(int(x[l].shape[0]), []).append(l)
         single = []
         for n_l, group in by_size.items():
-            sliced = all(_layer_array(v, group) is not None for v in (y_mean, x, f_bar, train_out))
+            # the batched call addresses a block by ONE row offset into the layer's arrays: every array must be a
+            # row-major 2-D array of which the region views are slices, at the same rows in all four
+            sliced = all(_layer_array(v, group) is not None for v in (y_mean, x, f_bar, train_out)) \
+                and _same_rows((y_mean, x, f_bar, train_out), group)
             if len(group) >= 2 and n_l <= BATCH_MAX_N and sliced:
                 self._fit_batched(group, y_mean, x, f_bar, train_out, shared_bias, shared_noise, keep_factors)
             else:

@@ -398,9 +398,9 @@ static __device__ __forceinline__ Mx<float>::acc_t mfma_k4(float a, float b, Mx<
 // scalar FMAs whose per-column coefficients every wave read as LDS broadcasts: 2 MB of LDS
 // return traffic per block, 1.1 us per 4 pivots of which the pivots themselves were 0.24 us.)
 // One block of BC = 4 pivots in the pivot wave (lane = row i), shared by the nine-wave and the four-wave
-// factorisation: takes the block's columns `nx` as gathered (updated through block p-2; rows of block p-1
-// gathered as ZERO: their slots restart there), applies block p-1's rank-4 update to them itself, eliminates
-// the 4 pivots and publishes the rank-4 update's two operands (hs_row: this row's left operand, UNMASKED --
+// factorisation: takes the block's columns `nx` as gathered (updated through block p-3; rows of blocks p-2 and
+// p-1 gathered as ZERO: their slots restart there), applies the rank-4 updates of blocks p-2 and p-1 to them
+// itself, eliminates the 4 pivots and publishes the rank-4 update's two operands (hs_row: this row's left operand, UNMASKED --
 // the tile waves zero the three entries of a block's own rows that lie below their pivots; cs: the
 // pivot-time columns, kept for all 64 pivots).
 //
@@ -425,17 +425,35 @@ template <> __device__ __forceinline__ double tiny_if<double>(double v, bool c)
 template <> __device__ __forceinline__ float tiny_if<float>(float v, bool c) { return c ? 0.0f : v; }
 
 template <typename T>
-static __device__ __forceinline__ void pivot_block(int p, T (&nx)[4], T (&cv)[4], T (&hsr)[4],
+static __device__ __forceinline__ void pivot_block(int p, T (&nx)[4], T (&cv)[4], T (&hsr)[4], T (&hsr2)[4],
                                                     T* __restrict__ hs_row, T* __restrict__ cs, int i)
 {
     constexpr int LS = SB + 2;
     constexpr int BC = 4;
     const int j0 = BC * p;
+    // The gathered columns carry the updates through block p-3 only (the tile waves hand them over BEFORE their
+    // own multiply of block p-2: see TileGroup::step): this wave applies blocks p-2 and p-1 itself.  The 4 x 4
+    // coefficients of a block = its pivot-time columns at the rows of block p, published in `cs` by this wave;
+    // uniform 16-byte LDS reads, in flight together with the gathered columns.  One chain of fused operations
+    // per column (fewest instructions).  Rows of block p-2 and p-1 arrive as zero (their slots restart there);
+    // a row of block p-1 takes nothing from block p-2 (not born yet: reset between the two updates).
+    if (p > 1) {
+        const T* sp = &cs[j0 * LS + j0 - 2 * BC];
+        T sm[BC][BC];
+#pragma unroll
+        for (int t2 = 0; t2 < BC; ++t2)
+#pragma unroll
+            for (int t = 0; t < BC; ++t) sm[t2][t] = sp[t2 * LS + t];
+        const bool rows_prev = (unsigned)(i - (j0 - BC)) < (unsigned)BC;
+#pragma unroll
+        for (int t2 = 0; t2 < BC; ++t2) {
+            T u = nx[t2];
+#pragma unroll
+            for (int t = 0; t < BC; ++t) u = fma(hsr2[t], sm[t2][t], u);
+            nx[t2] = tiny_if<T>(u, rows_prev);
+        }
+    }
     if (p > 0) {
-        // block p-1's update of block p's columns (the tile waves have not applied it to what was
-        // gathered).  The 4 x 4 coefficients = block p-1's pivot-time columns at the rows of block p: this
-        // wave published them in `cs` before the barrier; 8 uniform 16-byte LDS reads, in flight together
-        // with the gathered columns.  One chain of four fused operations per column (fewest instructions).
         const T* sp = &cs[j0 * LS + j0 - BC];
         T sm[BC][BC];
 #pragma unroll
@@ -476,8 +494,10 @@ static __device__ __forceinline__ void pivot_block(int p, T (&nx)[4], T (&cv)[4]
         hs_row[t] = nh[t];
         cp[t] = cv[t];
     }
-    // this wave's own copy of the left operand, for the next block's self-update: a row of THIS block takes
+    // this wave's own copies of the left operand, for the next two blocks' self-updates: a row of THIS block takes
     // nothing from the pivots above it (its slots right of the block are born at its own pivot)
+#pragma unroll
+    for (int t = 0; t < BC; ++t) hsr2[t] = hsr[t];
     const unsigned u = (unsigned)(i - j0);
     hsr[0] = tiny_if<T>(nh[0], u - 1u < 3u);
     hsr[1] = tiny_if<T>(nh[1], u - 2u < 2u);
@@ -539,7 +559,15 @@ struct TileGroup {
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[k][r] = cs[((BR0 + k) * 16 + X::crow(lane, r)) * LS + BCOL * 16 + (lane & 15)];
     }
-    // block p's rank-4 update of the group's tiles, then the gather of block p+2 (updated through block p):
+    // The gather of block p+2 for the pivot wave, THEN block p's rank-4 update of the group's tiles.
+    // Round 4: the gather comes FIRST, i.e. the columns leave with the updates through block p-1 only and the pivot
+    // wave applies two blocks itself.  Handing them over right behind this step's multiplies -- as rounds 1-3 did
+    // -- reads accumulators that a just-issued matrix-core instruction may not have written yet once OTHER waves'
+    // multiplies share the SIMD's matrix core (a four-wave workgroup beside a running trailing update, riders, the
+    // blocks of a batch): FP32, four 8-pass multiplies then sixteen LDS writes, beside an FP32 update: 3-27 % of
+    // whole factorisations wrong, always in rows 62 / 63 of a block's last 4 columns -- the last multiply's last
+    // registers; 800 idle cycles before the writes cured it, the compiler's wait states (counted from issue, for
+    // an uncontended core) did not.  Now the values handed over are a full barrier old.
     //   right operand = the pivot-time columns at this column block's rows (zero for columns that are final),
     //   left operand per tile = the pivot wave's -A[i][j] / d (a row of the block takes nothing from the pivots
     //   above it: the pivot wave publishes unmasked),
@@ -554,6 +582,18 @@ struct TileGroup {
         if (BCOL < bc0) return;                                   // uniform: every column of the group is final
         const int fcol = lane & 15, fk = lane >> 4;
         const int col = BCOL * 16 + fcol;
+        const int g0 = j0 + 2 * BC, gbc = g0 >> 4, gjb = g0 & 15;   // block p+2
+        if (p + 2 < NP && BCOL == gbc && fcol >= gjb && fcol < gjb + BC) {
+            T* pc = pcol + ((p & 1) * SB) * BC + (fcol - gjb);
+#pragma unroll
+            for (int k = 0; k < NB; ++k)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // rows of blocks p and p+1 restart from zero in these columns (pivot_block adds to what it is given)
+                    const int grow = (BR0 + k) * 16 + X::crow(lane, r);
+                    pc[grow * BC] = (grow >= j0 && grow < g0) ? (T)0 : acc[k][r];
+                }
+        }
 #pragma unroll
         for (int k = 0; k < NB; ++k)
             if (BR0 + k == bc0) {
@@ -576,18 +616,6 @@ struct TileGroup {
         }
 #pragma unroll
         for (int k = 0; k < NB; ++k) acc[k] = mfma_k4(af[k], bf, acc[k]);
-        const int g0 = j0 + 2 * BC, gbc = g0 >> 4, gjb = g0 & 15;   // block p+2
-        if (p + 2 < NP && BCOL == gbc && fcol >= gjb && fcol < gjb + BC) {
-            T* pc = pcol + ((p & 1) * SB) * BC + (fcol - gjb);
-#pragma unroll
-            for (int k = 0; k < NB; ++k)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    // rows of block p+1 restart from zero in these columns (pivot_block adds to what it is given)
-                    const int grow = (BR0 + k) * 16 + X::crow(lane, r);
-                    pc[grow * BC] = (grow >= j0 + BC && grow < g0) ? (T)0 : acc[k][r];
-                }
-        }
     }
 };
 
@@ -623,12 +651,12 @@ static __device__ __forceinline__ void diag_tail_lds(int tw, bool pivot, T* __re
     const int i = lane;
     if (pivot) {
         // ---- pivot wave: the recurrence and nothing else
-        T cv[BC], hsr[BC];                           // this row's block columns, left operand
+        T cv[BC], hsr[BC], hsr2[BC];                 // this row's block columns, left operands of the last two blocks
 #pragma unroll
-        for (int t = 0; t < BC; ++t) { cv[t] = (T)0; hsr[t] = (T)0; }
-        T first[2][BC];                              // blocks 0 and 1 straight from S
+        for (int t = 0; t < BC; ++t) { cv[t] = (T)0; hsr[t] = (T)0; hsr2[t] = (T)0; }
+        T first[3][BC];                              // blocks 0, 1 and 2 straight from S (zero above the diagonal)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 3; ++b)
 #pragma unroll
             for (int t = 0; t < BC; ++t) first[b][t] = cs[i * LS + b * BC + t];
         lds_barrier();                               // every wave has taken its share of S: cs may be overwritten
@@ -636,9 +664,9 @@ static __device__ __forceinline__ void diag_tail_lds(int tw, bool pivot, T* __re
         for (int p = 0; p < NP; ++p) {
             if (p == 8) STAMPW(16, DG_TW);
             T nx[BC];
-            if (p < 2) {
+            if (p < 3) {
 #pragma unroll
-                for (int t = 0; t < BC; ++t) nx[t] = (p == 0) ? first[0][t] : first[1][t];
+                for (int t = 0; t < BC; ++t) nx[t] = (p == 0) ? first[0][t] : (p == 1) ? first[1][t] : first[2][t];
             } else {
                 // this row's share of block p as gathered (two 16-byte reads, in flight during the FMAs below)
                 const T* gp = &pcol[((p & 1) * SB + i) * BC];
@@ -646,7 +674,7 @@ static __device__ __forceinline__ void diag_tail_lds(int tw, bool pivot, T* __re
                 for (int t = 0; t < BC; ++t) nx[t] = gp[t];
             }
 #if !defined(DIAG_EXP) || DIAG_EXP != 2      /* timing-only builds of tools/diag_probe.hip: 1 = tile waves idle, 2 = pivot wave idle */
-            pivot_block<T>(p, nx, cv, hsr, &hs[((p & 1) * SB + i) * BC], cs, i);
+            pivot_block<T>(p, nx, cv, hsr, hsr2, &hs[((p & 1) * SB + i) * BC], cs, i);
 #endif
             lds_barrier();
             if (p == 8) STAMPW(20, DG_TW);

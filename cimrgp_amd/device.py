@@ -122,16 +122,21 @@ def potrf_rows(kbuf, n, bbuf, m, ws=None, info=None):
     return ws, info
 
 
-def block_posterior(x, y, xs, ell, sf2, noise, kbuf, wbuf, ws, info, alpha, z, mean, var, add_noise=False, accumulate=False):
+def block_posterior(x, y, xs, ell, sf2, noise, kbuf, wbuf, ws, info, alpha, z, mean, var, add_noise=False, accumulate=False,
+                    scratch=None):
     """One block's whole posterior in ONE call (cimrgp_block_posterior, include/cimrgp.h): Gram matrix, factorisation with
     the cross-Gram rows and the targets carried, backward solve, predictive mean and variance -- the same kernels as the
     separate calls.  kbuf (n x ld), wbuf ((ns + q) x ld), ws / info as for potrf; alpha, z (n x q),
-    mean (ns x q), var (ns) are filled."""
+    mean (ns x q), var (ns) are filled.  ``scratch``: 2 q n elements (allocated here when not given: a caller that
+    must not allocate between two events -- bench.py's timed step -- passes its own)."""
     lib = _lib.load()
     n, d = x.shape
     q = y.shape[1]
     ns = 0 if xs is None else xs.shape[0]
-    scratch = torch.empty(2 * q * max(int(n), 1), dtype=x.dtype, device=x.device)
+    if scratch is None:
+        scratch = torch.empty(2 * q * max(int(n), 1), dtype=x.dtype, device=x.device)
+    elif scratch.numel() < 2 * q * max(int(n), 1) or scratch.dtype != x.dtype:
+        raise ValueError("scratch must hold 2 q n elements of the block's dtype")
     _lib.check(lib.cimrgp_block_posterior(_DT[x.dtype], _p(x), int(n), int(d), _p(y), int(q), _p(xs), int(ns), float(ell), float(sf2),
                                           float(noise), _p(kbuf), kbuf.stride(0), _p(ws), ws.numel(), _p(info), _p(wbuf),
                                           wbuf.stride(0), _p(alpha), _p(z), _p(scratch), _p(mean), _p(var), int(bool(add_noise)),
@@ -161,6 +166,23 @@ def solve_lt_batched(karena, n, ld, ws_arena, z):
     return z
 
 
+#: work areas of cimrgp_layer_fit (carried target rows, solve scratch) per (device, dtype, batch, q, n): the fit of a layer
+#: is enqueue-only, so they are not allocated per call; a new shape replaces the cached one (O(batch q n) elements)
+_LAYER_WORK = {}
+
+
+def _layer_work_areas(batch, q, n, ldr, dtype, device):
+    key = (str(device), dtype)
+    shape = (batch, q, n)
+    hit = _LAYER_WORK.get(key)
+    if hit is None or hit[0] != shape:
+        rows = torch.empty((batch, q, ldr), dtype=dtype, device=device)
+        scratch = torch.empty((batch, 2 * q * max(n, 1)), dtype=dtype, device=device)
+        hit = (shape, rows, scratch)
+        _LAYER_WORK[key] = hit
+    return hit[1], hit[2]
+
+
 def layer_fit(x, y, fbar, train_out, starts, n, ell, sf2, noise_fixed, noise_frac, noise_floor, shared_bias, shared_noise,
               karena, ws_arena, info, bias, noise, z, alpha):
     """The fit of ``batch`` equal-sized blocks of one layer in ONE call (cimrgp_layer_fit, include/cimrgp.h).
@@ -172,8 +194,7 @@ def layer_fit(x, y, fbar, train_out, starts, n, ell, sf2, noise_fixed, noise_fra
     q = int(y.shape[1])
     d = int(x.shape[1])
     ldr = padded_ld(n)
-    rows = torch.empty((batch, q, ldr), dtype=y.dtype, device=y.device)
-    scratch = torch.empty((batch, 2 * q * max(int(n), 1)), dtype=y.dtype, device=y.device)
+    rows, scratch = _layer_work_areas(batch, q, int(n), ldr, y.dtype, y.device)
     _lib.check(lib.cimrgp_layer_fit(_DT[y.dtype], _p(x), _p(y), _p(fbar), _p(train_out), _p(starts), batch, int(n), d, q,
                                     float(ell), float(sf2), float(noise_fixed), float(noise_frac), float(noise_floor),
                                     _p(shared_bias), _p(shared_noise), _p(karena), karena.stride(1), karena.stride(0),

@@ -51,3 +51,32 @@ def test_argument_errors_are_reported_not_crashed():
     assert rc < 0 and "length-scale" in _lib.last_error()
     with pytest.raises(_lib.CimrgpError):
         _lib.check(rc, "cimrgp_rbf_gram")
+
+
+def test_schedule_watchdog_is_not_reported_as_not_positive_definite():
+    """include/cimrgp.h: CIMRGP_INFO_WATCHDOG in *info says the factorisation's internal schedule gave up waiting
+    (a bounded device-side wait), not that a leading minor failed.  The reference's PD guard catches LinAlgError
+    and repairs the matrix (src/SanityCheck.py:59-65): a schedule failure must surface as RuntimeError instead."""
+    import numpy as np
+    import torch
+    from cimrgp_amd import device as dev
+    text = open(os.path.join(ROOT, "include", "cimrgp.h")).read()
+    m = re.search(r"#define\s+CIMRGP_INFO_WATCHDOG\s+(0x[0-9a-fA-F]+)", text)
+    assert m and int(m.group(1), 16) == dev.INFO_WATCHDOG == 2 ** 31 - 1
+    dev.raise_if_not_pd(0)
+    dev.raise_if_not_pd(torch.zeros(1, dtype=torch.int32))
+    with pytest.raises(np.linalg.LinAlgError, match="leading minor of order 5"):
+        dev.raise_if_not_pd(5)
+    with pytest.raises(RuntimeError, match="schedule watchdog"):
+        dev.raise_if_not_pd(dev.INFO_WATCHDOG)
+    with pytest.raises(RuntimeError, match="schedule watchdog"):
+        dev.raise_if_not_pd(torch.tensor([dev.INFO_WATCHDOG], dtype=torch.int32))
+    try:
+        dev.raise_if_not_pd(dev.INFO_WATCHDOG)
+    except np.linalg.LinAlgError:                      # RuntimeError is not a LinAlgError: the PD guard must not see it
+        raise AssertionError("watchdog mapped to LinAlgError")
+    except RuntimeError:
+        pass
+    # the flag crosses ranks inside a floating-point all-reduce (MRGP._fit): float32 rounds 2^31 - 1 up, sums grow
+    assert dev.is_watchdog(np.float32(dev.INFO_WATCHDOG)) and dev.is_watchdog(float(dev.INFO_WATCHDOG) + 4096.0)
+    assert not dev.is_watchdog(0) and not dev.is_watchdog(8 * 262144)

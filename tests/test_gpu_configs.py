@@ -344,7 +344,11 @@ def test_bench_step_under_rccl_world_of_one():
     assert rccl2["config"]["rows_queues"] == 2 and rccl1["config"]["rows_queues"] == 1
     # a live RCCL communicator (its stream included) must not disturb the step: within 15 % of the plain run
     assert rccl2["ms_per_step"] < 1.15 * plain["ms_per_step"]
-    assert rccl2["stage_ms"]["reduce"] < 1.0
+    # the timed step is ONE C call; the collective is started at its end and hidden behind the next step: a step that
+    # waits for it inside (drained_step_ms) is reported beside the headline and may not cost more than 1 ms extra
+    assert plain["reduce_overlapped"] is False and plain["drained_step_ms"] is None
+    assert rccl2["reduce_overlapped"] is True and rccl2["drained_step_ms"] < rccl2["ms_per_step"] + 1.0
+    assert "cimrgp_block_posterior" in plain["step_is"]
 
 
 def test_non_pd_block_raises_on_every_rank(ca, tmp_path):

@@ -151,6 +151,75 @@ def test_potrf_f32(dev, n):
     assert _relerr(lmat @ lmat.T, k) < 2e-5
 
 
+@pytest.mark.parametrize("n,m", [(5632, 0), (5632, 130), (8192, 0), (8192, 130), (16384, 0), (16384, 130)])
+def test_potrf_f32_lookahead_backward_error(dev, n, m):
+    """FP32 ABOVE the one-queue limit (look-ahead schedule, persistent / paired far updates, carried rows on their own
+    queues): backward error of the factor, |L L^T - K|_F / |K|_F < 8 n eps32 (the factor is formed in FP64 from the
+    FP32 L on the GPU), and the carried rows W = B L^-T against the FP64 oracle at noise 0.1 -- a wrong tile shows
+    as an error of order one, conditioning (~n / noise) as 1e-3."""
+    rng = np.random.default_rng(n + m)
+    x = np.sort(rng.uniform(-2.0, 2.0, size=(n, 1)), axis=0)
+    ell, sf2, noise = 0.05, 1.0, 0.1
+    xd = dev.to_device(x, torch.float32, "cuda")
+    kbuf = dev.rbf_gram(xd, ell, sf2, noise, lower_only=True)
+    k64 = torch.tril(kbuf[:n, :n]).double()
+    k64 = k64 + torch.tril(k64, -1).t()
+    if m:
+        bmat = rng.normal(size=(m, n))
+        bbuf = dev.alloc_matrix(m, n, torch.float32, "cuda")
+        bbuf[:m, :n] = torch.from_numpy(bmat).to("cuda", torch.float32)
+        b64 = bbuf[:m, :n].double().cpu().numpy()                  # the rows as the kernel saw them
+        ws, info = dev.potrf_rows(kbuf, n, bbuf, m)
+    else:
+        ws, info = dev.potrf(kbuf, n)
+    assert int(info.item()) == 0
+    l64 = torch.tril(kbuf[:n, :n]).double()
+    resid = float(torch.linalg.norm(l64 @ l64.t() - k64) / torch.linalg.norm(k64))
+    eps32 = float(np.finfo(np.float32).eps)
+    assert resid < 8 * n * eps32, resid
+    assert resid < 64 * np.sqrt(n) * eps32, resid                  # what a blocked factorisation really delivers
+    if m:
+        lref, iref = oracle.potrf_lower(k64.cpu().numpy())
+        assert iref == 0
+        want = sla.solve_triangular(lref, b64.T, lower=True).T      # B L^-T in FP64, from the FP32 inputs
+        got = bbuf[:m, :n].double().cpu().numpy()
+        err = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+        assert err < 2e-3, err
+
+
+def test_more_caller_streams_than_contexts(dev):
+    """Ten caller streams factor matrices above the one-queue limit at the same time: beyond the eight look-ahead
+    contexts of a device callers share a context by hash -- and must not share its gate counter (only the context's
+    owner stream uses the gate; round 3 let any caller of the first context reset and count on it).  Every factor
+    against LAPACK."""
+    n = 5376
+    rng = np.random.default_rng(3)
+    xs = [np.sort(rng.uniform(-2.0, 2.0, size=(n, 1)), axis=0) for _ in range(2)]
+    ell, sf2, noise = 0.05, 1.0, 0.01
+    refs = []
+    for x in xs:
+        lref, iref = oracle.potrf_lower(oracle.rbf_gram(x, None, ell, sf2, noise))
+        assert iref == 0
+        refs.append(lref)
+    streams = [torch.cuda.Stream() for _ in range(10)]
+    xds = [dev.to_device(x, torch.float64, "cuda") for x in xs]
+    bufs, infos = [], []
+    for rep in range(2):                                    # second round: every stream's context exists already
+        bufs, infos = [], []
+        torch.cuda.synchronize()
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                kbuf = dev.rbf_gram(xds[i % 2], ell, sf2, noise, lower_only=True)
+                ws, info = dev.potrf(kbuf, n)
+                bufs.append((kbuf, ws))
+                infos.append(info)
+        torch.cuda.synchronize()
+        for i in range(len(streams)):
+            assert int(infos[i].item()) == 0, (rep, i, int(infos[i].item()))
+            lmat = torch.tril(bufs[i][0][:n, :n]).cpu().numpy()
+            assert np.max(np.abs(lmat - refs[i % 2])) / np.max(np.abs(refs[i % 2])) < 1e-10, (rep, i)
+
+
 def test_potrf_reports_first_bad_pivot(dev):
     x = np.array([[0.0], [0.5], [0.5], [1.0]] + [[2.0 + i] for i in range(70)])   # duplicated point, no noise
     _, _, _, info = _factor(dev, x, 1.0, 1.0, 0.0, torch.float64)

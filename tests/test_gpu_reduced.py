@@ -158,6 +158,23 @@ def test_model_matches_reference_fit(ca, golden_dir, tag):
     assert _rel(model.get_central_moment2(z["xt"], idx_t), z["pred_var_index"]) < tol
 
 
+@pytest.mark.parametrize("tag", ["fi_r2", "ci_r2"])
+def test_test_likelihood_matches_reference(ca, golden_dir, tag):
+    """``get_test_likelihood`` (reference: MRGP.py:825-831) against the reference's own values, both call forms
+    (no index set: resolution 0 / region 0; with the test index set), on the models of reference_model_<tag>.npz
+    (tests/golden/make_golden_likelihood.py)."""
+    z = np.load(os.path.join(golden_dir, "reference_model_%s.npz" % tag))
+    g = np.load(os.path.join(golden_dir, "reference_likelihood.npz"))
+    res = int(z["resolution"])
+    model = _build(ca, z["x"], z["y"], res, int(z["n_basis"]), bool(z["forced_independence"]))
+    model.fit(5, None)
+    xt, yt = g[tag + "_xt"], g[tag + "_yt"]
+    ll_global = model.get_test_likelihood([xt, yt])
+    ll_index = model.get_test_likelihood([xt, yt], ca.IndexSetUniform(xt.shape[0], res, 2))
+    assert abs(ll_global - float(g[tag + "_ll_global"])) < 1e-8 * abs(float(g[tag + "_ll_global"]))
+    assert abs(ll_index - float(g[tag + "_ll_index"])) < 1e-8 * abs(float(g[tag + "_ll_index"]))
+
+
 @pytest.mark.parametrize("forced", [True, False])
 def test_model_matches_oracle_2d_inputs(ca, forced):
     """Other shapes than the goldens: 2-D inputs, 3 outputs, ragged blocks, widened intervals,

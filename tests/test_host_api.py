@@ -191,3 +191,22 @@ def test_hilbert_order_makes_compact_regions():
         assert extent < 1.6 * 2.0 / np.sqrt(k)      # longest side close to the ideal square's 2/sqrt(k)
     strips = np.mean([np.max(np.ptp(b, axis=0)) for b in np.split(x[np.argsort(x[:, 0])], 128)])
     assert strips > 1.9
+
+
+def test_batched_fit_needs_the_same_row_ranges_in_every_layer_array():
+    """Posteriors._fit_batched addresses a block by ONE row offset into the layer's arrays (cimrgp_layer_fit): region
+    views of x, y, f_bar and train_out must be the same row ranges of their arrays, or the layer takes the
+    block-by-block path.  A y that is itself a view at a non-zero storage offset is the case that used to raise."""
+    import torch
+    from cimrgp_amd.Posteriors import _layer_array, _same_rows
+    n, q = 12, 2
+    bounds = [(0, 6), (6, 12)]
+    x_all = torch.zeros((n, 1), dtype=torch.float64)
+    y_all = torch.zeros((n, q), dtype=torch.float64)
+    big = torch.zeros((n + 3, q), dtype=torch.float64)
+    y_off = big[3:]                                           # same shape, storage offset 3 rows
+    views = lambda t: [t[a:b] for a, b in bounds]
+    group = [0, 1]
+    assert all(_layer_array(v, group) is not None for v in (views(x_all), views(y_all), views(y_off)))
+    assert _same_rows((views(y_all), views(x_all), views(y_all)), group)
+    assert not _same_rows((views(y_off), views(x_all), views(y_all)), group)

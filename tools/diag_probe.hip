@@ -7,6 +7,7 @@
 #include "../cimrgp_amd/csrc/potrf.hip"
 #include "../cimrgp_amd/csrc/gemm_nt.hip"
 #include <cmath>
+#include <cstring>
 #include <vector>
 using namespace cimrgp;
 namespace cimrgp {
@@ -108,6 +109,97 @@ int main()
                 printf("\n");
             }
             for (int r = 16; r < 26; ++r) printf("row %d col 20: nine %.6f four %.6f | col 16: %.6f %.6f\n", r, out[0][r * 64 + 20], out[1][r * 64 + 20], out[0][r * 64 + 16], out[1][r * 64 + 16]);
+        }
+    }
+    // repeatability: the same block factored 2000 times by each form, FP32 and FP64 (any difference between two
+    // runs of the SAME kernel on the SAME input is a race inside it)
+    {
+        std::vector<float> hf((size_t)64 * 64);
+        for (int i = 0; i < 64; ++i) for (int j = 0; j < 64; ++j) hf[i * 64 + j] = (float)h[(size_t)(i + 300) * ld + j + 300];
+        float *dF, *dwsF, *dref; double* dwsD2;
+        hipMalloc(&dF, 64 * 64 * 4 * 2); hipMalloc(&dwsF, 64 * 64 * 4); hipMalloc(&dref, 64 * 64 * 4 * 2); hipMalloc(&dwsD2, 64 * 64 * 8);
+        for (int form = 0; form < 2; ++form) {
+            int mism = 0;
+            std::vector<float> ref(64 * 64 * 2), got(64 * 64 * 2);
+            for (int it = 0; it < 2000; ++it) {
+                hipMemcpy(dF, hf.data(), 64 * 64 * 4, hipMemcpyHostToDevice); hipMemset(dinfo, 0, 4);
+                if (form == 0) hipLaunchKernelGGL((k_diag64<float>), dim3(1), dim3(DG_NT), 0, 0, dF, (int64_t)64, 64, (const float*)dF, 0, dwsF, dinfo, 0, (int64_t)0, (int64_t)0, (int64_t)0, no_riders<float>());
+                else hipLaunchKernelGGL((k_diag64q<float>), dim3(1), dim3(Q_NT), 0, 0, dF, (int64_t)64, 64, (const float*)dF, 0, dwsF, dinfo, 0, (int64_t)0, (int64_t)0, (int64_t)0, no_riders<float>());
+                hipMemcpy(got.data(), dF, 64 * 64 * 4, hipMemcpyDeviceToHost);
+                hipMemcpy(got.data() + 64 * 64, dwsF, 64 * 64 * 4, hipMemcpyDeviceToHost);
+                if (it == 0) ref = got;
+                else {
+                    bool same = true;
+                    for (int r = 0; r < 64 && same; ++r) for (int c = 0; c <= r; ++c)
+                        if (memcmp(&ref[r * 64 + c], &got[r * 64 + c], 4) || memcmp(&ref[4096 + r * 64 + c], &got[4096 + r * 64 + c], 4)) { same = false; break; }
+                    if (!same) ++mism;
+                }
+            }
+            printf("FP32 %s: %d of 1999 repetitions differ from the first\n", form == 0 ? "k_diag64 " : "k_diag64q", mism);
+        }
+        for (int form = 0; form < 2; ++form) {
+            int mism = 0;
+            std::vector<double> ref(64 * 64), got(64 * 64), blk(64 * 64);
+            for (int i = 0; i < 64; ++i) for (int j = 0; j < 64; ++j) blk[i * 64 + j] = h[(size_t)(i + 300) * ld + j + 300];
+            double* dD; hipMalloc(&dD, 64 * 64 * 8);
+            for (int it = 0; it < 2000; ++it) {
+                hipMemcpy(dD, blk.data(), 64 * 64 * 8, hipMemcpyHostToDevice); hipMemset(dinfo, 0, 4);
+                if (form == 0) hipLaunchKernelGGL((k_diag64<double>), dim3(1), dim3(DG_NT), 0, 0, dD, (int64_t)64, 64, (const double*)dD, 0, dwsD2, dinfo, 0, (int64_t)0, (int64_t)0, (int64_t)0, no_riders<double>());
+                else hipLaunchKernelGGL((k_diag64q<double>), dim3(1), dim3(Q_NT), 0, 0, dD, (int64_t)64, 64, (const double*)dD, 0, dwsD2, dinfo, 0, (int64_t)0, (int64_t)0, (int64_t)0, no_riders<double>());
+                hipMemcpy(got.data(), dD, 64 * 64 * 8, hipMemcpyDeviceToHost);
+                if (it == 0) ref = got;
+                else {
+                    bool same = true;
+                    for (int r = 0; r < 64 && same; ++r) for (int c = 0; c <= r; ++c) if (memcmp(&ref[r * 64 + c], &got[r * 64 + c], 8)) { same = false; break; }
+                    if (!same) ++mism;
+                }
+            }
+            printf("FP64 %s: %d of 1999 repetitions differ from the first\n", form == 0 ? "k_diag64 " : "k_diag64q", mism);
+        }
+    }
+    // repeatability of a whole panel chain (first diagonal block, three links, last panel solve) in the four-wave
+    // and the nine-wave form, FP32, 1024 rows below: every repetition must reproduce the first bit for bit
+    {
+        const int nn = 1280, lds = 1296;
+        std::vector<float> hf((size_t)nn * lds, 0.f), ref((size_t)nn * 256), got((size_t)nn * 256);
+        for (int i = 0; i < nn; ++i) for (int j = 0; j <= i; ++j) hf[(size_t)i * lds + j] = (float)(std::exp(-0.5 * (i - j) * (i - j) / 900.0) + (i == j ? 0.1 : 0.0));
+        float *dM, *dW; hipMalloc(&dM, hf.size() * 4); hipMalloc(&dW, ((size_t)(nn / 64) * 4096 + (size_t)(nn / 256) * 65536) * 4);
+        for (int alone = 0; alone < 2; ++alone) {
+            int mism = 0;
+            for (int it = 0; it < 400; ++it) {
+                hipMemcpy(dM, hf.data(), hf.size() * 4, hipMemcpyHostToDevice); hipMemset(dinfo, 0, 4);
+                panel_chain<float>(dM, nn, lds, dW, dinfo, 0, 256, (float*)nullptr, 0, 0, PotrfBatch(), (hipStream_t)0, "probe", alone != 0);
+                hipDeviceSynchronize();
+                for (int r = 0; r < nn; ++r) hipMemcpy(&got[(size_t)r * 256], dM + (size_t)r * lds, 256 * 4, hipMemcpyDeviceToHost);
+                if (it == 0) ref = got;
+                else if (memcmp(ref.data(), got.data(), ref.size() * 4)) ++mism;
+            }
+            int32_t info; hipMemcpy(&info, dinfo, 4, hipMemcpyDeviceToHost);
+            printf("FP32 panel chain, %s form: %d of 399 repetitions differ from the first (info %d)\n", alone ? "nine-wave" : "four-wave", mism, info);
+        }
+    }
+    // the same panel chain BESIDE a running FP32 trailing update on another stream (the look-ahead's situation)
+    {
+        const int nn = 1280, lds = 1296, mu = 6144, ldu = 6160;
+        std::vector<float> hf((size_t)nn * lds, 0.f), ref((size_t)nn * 256), got((size_t)nn * 256);
+        for (int i = 0; i < nn; ++i) for (int j = 0; j <= i; ++j) hf[(size_t)i * lds + j] = (float)(std::exp(-0.5 * (i - j) * (i - j) / 900.0) + (i == j ? 0.1 : 0.0));
+        float *dM, *dW, *dC, *dA; hipMalloc(&dM, hf.size() * 4); hipMalloc(&dW, ((size_t)(nn / 64) * 4096 + (size_t)(nn / 256) * 65536) * 4);
+        hipMalloc(&dC, (size_t)mu * ldu * 4); hipMalloc(&dA, (size_t)mu * 256 * 4);
+        hipMemset(dC, 0, (size_t)mu * ldu * 4); hipMemset(dA, 0, (size_t)mu * 256 * 4);
+        hipStream_t s1, s2; hipStreamCreateWithFlags(&s1, hipStreamNonBlocking); hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+        for (int alone = 0; alone < 2; ++alone) {
+            int mism = 0;
+            for (int it = 0; it < 300; ++it) {
+                hipMemcpy(dM, hf.data(), hf.size() * 4, hipMemcpyHostToDevice); hipMemset(dinfo, 0, 4);
+                hipDeviceSynchronize();
+                if (it) gemm_nt_sub<float>(dC, ldu, dA, 256, dA, 256, mu, mu, 256, true, s2);      // the co-runner (not for the reference run)
+                panel_chain<float>(dM, nn, lds, dW, dinfo, 0, 256, (float*)nullptr, 0, 0, PotrfBatch(), s1, "probe", alone != 0);
+                hipDeviceSynchronize();
+                for (int r = 0; r < nn; ++r) hipMemcpy(&got[(size_t)r * 256], dM + (size_t)r * lds, 256 * 4, hipMemcpyDeviceToHost);
+                if (it == 0) ref = got;
+                else if (memcmp(ref.data(), got.data(), ref.size() * 4)) ++mism;
+            }
+            printf("FP32 panel chain beside a running update, %s form: %d of 299 repetitions differ from the undisturbed first\n", alone ? "nine-wave" : "four-wave", mism);
         }
     }
     // un-stamped rate: 200 back-to-back launches of each diagonal kernel on a 64 x 64 block (kprev = 0)
