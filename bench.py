@@ -199,7 +199,8 @@ def run_config(args, world, rank, rehearsal):
             fits.append(t1 - t0)
             preds.append(t2 - t1)
             layer_ms = model.layer_fit_ms()
-        owner = [o.tolist() for o in model.owner]
+        owner = [np.asarray(o).tolist() for o in model.owner]
+        first_local = int(model._first_local)
         n_regions, n_samps = model.n_regions, model.n_samps
         del model
     fit_s, pred_s = float(np.median(fits)), float(np.median(preds))
@@ -225,7 +226,9 @@ def run_config(args, world, rank, rehearsal):
             "config": {"workload": name + ", q=2 outputs, N/4=%d test points, noise 0.01" % ns, "root_policy": policy,
                        "regions_per_layer": n_regions, "block_sizes_per_layer": [sorted(set(v)) for v in n_samps],
                        "blocks_per_rank": [[int(sum(1 for o in layer if o == r)) for layer in owner] for r in range(world)],
-                       "parallelism": "blocks sharded over ranks (LPT); 1 all-reduce per layer + 1 at prediction",
+                       "parallelism": "nested block ownership (cimrgp_amd.dist.plan_layers): layers below first_local_layer by LPT with "
+                                      "1 all-reduce each, the others exchange nothing during the fit; 1 all-reduce after the sweep + 1 at prediction",
+                       "first_local_layer": first_local,
                        "backend": (rehearsal or "nccl") if td.is_initialized() else "none"},
             "fit_s": fit_s, "predict_s": pred_s, "layer_fit_ms": layer_ms,
             "cholesky_flops": float(sum(sum(float(m) ** 3 / 3 for m in layer) for layer in n_samps)),

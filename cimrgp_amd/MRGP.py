@@ -153,7 +153,8 @@ class MultiResolutionGaussianProcess(object):
         self.n_samps = [[int(b - a) for a, b in layer] for layer in index_set_obj.bounds]
         self.x = [[self._x_dev[int(a):int(b)] for a, b in index_set_obj.bounds[j]] for j in range(self.n_layers)]
         self._y = dev.to_device(y_train, self.dtype, self.device)
-        self.owner = [dist.assign_blocks(self.n_samps[j], self.world_size) for j in range(self.n_layers)]
+        # nested ownership: layers >= self._first_local exchange nothing during the fit (dist.plan_layers)
+        self.owner, self._first_local = dist.plan_layers(index_set_obj.bounds, self.world_size)
 
         self.posterior_obj = [DensePosterior(self.n_regions[j], self.dy, self.spectral_density_obj[j],
                                              noise_region_specific, bias_region_specific)
@@ -203,11 +204,20 @@ class MultiResolutionGaussianProcess(object):
         f_bar = torch.zeros_like(self._y)
         self._layer_events = [torch.cuda.Event(enable_timing=True) for _ in range(self.n_layers + 1)]
         failed = torch.zeros(self.n_layers, dtype=self.dtype, device=self.device)
+        # Layers from self._first_local on are LOCAL (dist.plan_layers): a rank's blocks lie inside row ranges whose
+        # coarser predictions it computed itself, so the residual chain needs no exchange there; their predictions
+        # (and failure flags) are assembled on every rank by ONE all-reduce after the sweep.
+        local_from = self._first_local if self.world_size > 1 else self.n_layers
+        n_local = max(0, self.n_layers - local_from) if self.world_size > 1 else 0
+        tail = torch.zeros(n_local * (n * q + 1), dtype=self.dtype, device=self.device) if n_local else None
         for j in range(self.n_layers):
             self._layer_events[j].record()
             self._f_bar_layers[j] = f_bar
             # [layer's training-point prediction (N x q) | failure flag]: ONE buffer, one collective
-            buf = torch.zeros(n * q + 1, dtype=self.dtype, device=self.device)
+            if j >= local_from and n_local:
+                buf = tail[(j - local_from) * (n * q + 1):(j - local_from + 1) * (n * q + 1)]
+            else:
+                buf = torch.zeros(n * q + 1, dtype=self.dtype, device=self.device)
             layer_pred = buf[:n * q].view(n, q)
             owned = self._owned(j)
             self.posterior_obj[j].update_scale_given_axis(
@@ -217,10 +227,20 @@ class MultiResolutionGaussianProcess(object):
             # would leave the others blocked in the collective): the blocks' LAPACK-style info
             # words ride in the same all-reduce and every rank raises after it.
             self.posterior_obj[j].failure_flag(owned, out=buf[n * q:])
-            # residual chain (Stats.py:126-157): every rank needs the whole layer's prediction
-            dist.allreduce_sum_(buf, self.group)
-            f_bar = f_bar + layer_pred
-            failed[j:j + 1].copy_(buf[n * q:])               # read ONCE, after the sweep: the fit stays enqueue-only
+            if not (j >= local_from and n_local):
+                # residual chain (Stats.py:126-157): every rank needs the whole layer's prediction
+                dist.allreduce_sum_(buf, self.group)
+                failed[j:j + 1].copy_(buf[n * q:])           # read ONCE, after the sweep: the fit stays enqueue-only
+            f_bar = f_bar + layer_pred                       # local layers: valid on this rank's own ranges, all it reads
+        if n_local:
+            dist.allreduce_sum_(tail, self.group)
+            # the latent function of every layer, now complete on every rank
+            f_bar = self._f_bar_layers[local_from]
+            for j in range(local_from, self.n_layers):
+                part = tail[(j - local_from) * (n * q + 1):(j - local_from + 1) * (n * q + 1)]
+                self._f_bar_layers[j] = f_bar
+                f_bar = f_bar + part[:n * q].view(n, q)
+                failed[j:j + 1].copy_(part[n * q:])
         self._layer_events[self.n_layers].record()
         # (a host read per layer made the device wait for the host's enqueue of the next layer: 2-3 ms on the
         # fine layers of config 4.  After a failed factorisation the later layers run on garbage -- harmless:

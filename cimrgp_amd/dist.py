@@ -3,8 +3,10 @@
 One process per GPU (``torch.distributed``; backend "nccl" is RCCL on ROCm,
 "gloo" in the CPU tests).  Blocks of one layer are independent; layers form a
 short chain through the residual f_bar (Stats.py:126-157).  Communication:
-  * fit: one all-reduce per layer of the layer's training-point prediction
-    (N x q, disjoint slices summed) so every rank holds f_bar for the next layer;
+  * fit: ownership is NESTED (plan_layers): from the first layer with at least as many regions as ranks on, a
+    rank fits the blocks inside its own row ranges and needs nobody else's predictions; only the coarser layers
+    exchange (one all-reduce each of the layer's training-point prediction, N x q, disjoint slices summed), and ONE
+    all-reduce after the sweep assembles the local layers' predictions (and the blocks' failure flags) everywhere;
   * predict: ONE all-reduce of the fused [mean | var] buffer (N* x (q+1)) --
     the sum over resolutions of MRGP.py:802-803.
 Payloads are a few MiB: latency-bound on xGMI, so a single fused buffer per
@@ -37,6 +39,47 @@ def assign_blocks(sizes, world_size):
         owner[l] = r
         load[r] += sizes[l] ** 3
     return owner
+
+
+def plan_layers(bounds, world_size):
+    """Ownership of every (resolution, region) block, and the first layer from which the residual chain is LOCAL.
+
+    ``bounds``: per layer an array of (start, stop) rows.  The regions of the reference's uniform index set are
+    nested contiguous ranges (IndexSetGenerator.py:51-65).  Let the ANCHOR be the first layer with at least
+    ``world_size`` regions: its regions are dealt to the ranks as contiguous runs of equal cost (n^3), and every
+    region of a finer layer goes to the rank that owns the anchor region containing it.  A rank then fits, in every
+    layer from the anchor on, exactly the blocks inside its own row ranges, whose targets need the coarser layers'
+    predictions on those ranges only -- its own: no exchange per layer.  The layers above the anchor
+    have fewer blocks than ranks: longest-processing-time assignment, one all-reduce each.
+
+    Returns (owners, first_local): owners[j][l] = rank; layers j >= first_local exchange nothing during the fit
+    (first_local = number of layers when the regions do not nest, e.g. a sample count the divider does not divide:
+    then every layer is assigned by LPT and exchanged, as before)."""
+    n_layers = len(bounds)
+    lpt = [assign_blocks([int(b) - int(a) for a, b in layer], world_size) for layer in bounds]
+    if world_size <= 1:
+        return lpt, n_layers
+    anchor = next((j for j in range(n_layers) if len(bounds[j]) >= world_size), None)
+    if anchor is None:
+        return lpt, n_layers
+    ab = [(int(a), int(b)) for a, b in bounds[anchor]]
+    # contiguous runs of (nearly) equal cost: region l goes to the rank whose share of the total cost its midpoint falls in
+    cost = np.asarray([float(b - a) ** 3 for a, b in ab])
+    mid = np.cumsum(cost) - 0.5 * cost
+    a_owner = np.minimum((mid / cost.sum() * world_size).astype(np.int64), world_size - 1)
+    if len(set(a_owner.tolist())) < world_size:            # degenerate costs: fall back to equal counts
+        a_owner = (np.arange(len(ab)) * world_size) // len(ab)
+    owners = list(lpt[:anchor]) + [a_owner]
+    starts = np.asarray([a for a, _ in ab])
+    for j in range(anchor + 1, n_layers):
+        own = np.zeros(len(bounds[j]), dtype=np.int64)
+        for l, (a, b) in enumerate(bounds[j]):
+            k = int(np.searchsorted(starts, int(a), side="right")) - 1
+            if k < 0 or int(b) > ab[k][1]:                 # not inside one anchor region: the layers do not nest
+                return lpt, n_layers
+            own[l] = a_owner[k]
+        owners.append(own)
+    return owners, anchor
 
 
 def allreduce_sum_(tensor, group=None, force=False):

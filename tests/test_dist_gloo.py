@@ -164,3 +164,111 @@ def test_rank_local_failure_is_raised_on_every_rank(tmp_path):
     seen = [open(os.path.join(str(tmp_path), "seen%d.txt" % r)).read() for r in range(2)]
     assert seen[0].startswith("remote:") and seen[0].endswith("|2")
     assert seen[1].startswith("own:Matrix is not positive definite") and seen[1].endswith("|2")
+
+
+# ---------------------------------------------------------------------------------- nested ownership
+def _nested_problem(world):
+    import oracle
+    rng = np.random.default_rng(9)
+    n, res = (256, 2) if world == 2 else (512, 4)
+    x = np.sort(rng.uniform(-1.7, 1.7, size=(n, 1)), axis=0)
+    y = np.hstack([np.sin(3 * x), np.cos(5 * x)]) + 0.1 * rng.normal(size=(n, 2))
+    bounds = oracle.index_bounds_uniform(n, res, 2)
+    specs = [oracle.DenseLayerSpec(1.0 / 2 ** j, 1.0, None) for j in range(res + 1)]
+    return x, y, bounds, specs
+
+
+def _nested_worker(rank, world, port, out_dir):
+    """MRGP._fit's communication schedule (cimrgp_amd/MRGP.py) with the oracle as the per-block arithmetic:
+    layers below dist.plan_layers' `first_local` exchange per layer, the others not at all; ONE all-reduce after
+    the sweep assembles the local layers' predictions."""
+    sys.path.insert(0, ROOT)
+    import oracle
+    from cimrgp_amd import dist
+    td.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    x, y, bounds, specs = _nested_problem(world)
+    owners, first_local = dist.plan_layers(bounds, world)
+    f_bar = np.zeros_like(y)
+    f_layers, tail, n_coll = [], [], 0
+    for j, layer in enumerate(bounds):
+        f_layers.append(f_bar.copy())
+        layer_pred = torch.zeros(y.shape, dtype=torch.float64)
+        for l, (a, b) in enumerate(layer):
+            if owners[j][l] != rank:
+                continue
+            resid = (y - f_bar)[a:b]
+            bias = resid.mean(axis=0)
+            noise = oracle.mrgp._noise_from_targets(resid, specs[j])
+            fit = oracle.block_fit(x[a:b], resid - bias, specs[j].ell, specs[j].sf2, noise)
+            layer_pred[a:b] = torch.from_numpy(resid - noise * fit["alpha"])
+        if j < first_local:
+            dist.allreduce_sum_(layer_pred)
+            n_coll += 1
+        else:
+            tail.append(layer_pred)
+        f_bar = f_bar + layer_pred.numpy()
+    if tail:
+        stacked = torch.stack(tail)
+        dist.allreduce_sum_(stacked)
+        n_coll += 1
+        f_bar = f_layers[first_local].copy()
+        for k, j in enumerate(range(first_local, len(bounds))):
+            f_layers[j] = f_bar.copy()
+            f_bar = f_bar + stacked[k].numpy()
+    np.savez(os.path.join(out_dir, "nested%d.npz" % rank), f_bar=f_bar, f_layers=np.stack(f_layers),
+             owners=np.concatenate([np.asarray(o) for o in owners]), first_local=first_local, n_coll=n_coll)
+    td.destroy_process_group()
+
+
+def _check_nested(tmp_path, world, want_first_local, want_blocks_rank0):
+    import oracle
+    port = _free_port()
+    mp.spawn(_nested_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    x, y, bounds, specs = _nested_problem(world)
+    _, f_bar = oracle.mrgp_fit(x, y, bounds, specs)
+    got = [np.load(os.path.join(str(tmp_path), "nested%d.npz" % r)) for r in range(world)]
+    for g in got:
+        assert int(g["first_local"]) == want_first_local
+        assert int(g["n_coll"]) == want_first_local + 1            # one per exchanged layer + ONE for all the local ones
+        np.testing.assert_array_equal(g["owners"], got[0]["owners"])          # every rank computes the same plan
+        np.testing.assert_allclose(g["f_bar"], f_bar, rtol=1e-12, atol=1e-13)    # = the single-process chain
+        np.testing.assert_array_equal(g["f_layers"], got[0]["f_layers"])      # every layer's latent function, everywhere
+    from cimrgp_amd import dist
+    owners, _ = dist.plan_layers(bounds, world)
+    assert [int((np.asarray(o) == 0).sum()) for o in owners] == want_blocks_rank0
+
+
+def test_nested_ownership_two_ranks_skips_the_per_layer_exchange(tmp_path):
+    _check_nested(tmp_path, 2, 1, [1, 1, 2])
+
+
+def test_nested_ownership_eight_ranks(tmp_path):
+    _check_nested(tmp_path, 8, 3, [1, 1, 1, 1, 2])
+
+
+def test_plan_layers_blocks_per_rank_of_the_baseline_configs():
+    """BASELINE configs[2] (N = 65536, the reference's index set: 1, 2, 4, 8, 16 regions) and configs[3] (N = 262144,
+    root policy: 8 ... 128 regions) on 1, 2, 4 and 8 ranks: blocks per rank and layer, the first local layer, and that
+    every finer block sits on the rank owning the range around it (src/IndexSetGenerator.py:51-65 nests the ranges)."""
+    from cimrgp_amd import dist
+    from cimrgp_amd.IndexSetGenerator import IndexSetUniform
+    idx3 = IndexSetUniform(65536, 4, 2)
+    idx4 = IndexSetUniform(262144, 4, 2, first_divider_power=3)
+    for world, first3 in [(1, 5), (2, 1), (4, 2), (8, 3)]:
+        owners, first = dist.plan_layers(idx3.bounds, world)
+        assert first == first3
+        per_rank = [[int((np.asarray(o) == r).sum()) for o in owners] for r in range(world)]
+        if world == 8:
+            assert per_rank[0] == [1, 1, 1, 1, 2] and per_rank[1] == [0, 1, 1, 1, 2] and per_rank[4] == [0, 0, 0, 1, 2]
+        for j in range(first, 4):                       # nesting: a block's children live on its rank
+            for l, (a, b) in enumerate(idx3.bounds[j + 1]):
+                parent = next(k for k, (pa, pb) in enumerate(idx3.bounds[j]) if pa <= a and b <= pb)
+                assert owners[j + 1][l] == owners[j][parent]
+    for world in (1, 2, 4, 8):
+        owners, first = dist.plan_layers(idx4.bounds, world)
+        assert first == (5 if world == 1 else 0)
+        per_rank = [[int((np.asarray(o) == r).sum()) for o in owners] for r in range(world)]
+        assert all(p == [8 // world, 16 // world, 32 // world, 64 // world, 128 // world] for p in per_rank)
+    # a sample count the divider does not divide: the ranges do not nest -> every layer by LPT, every layer exchanged
+    owners, first = dist.plan_layers(IndexSetUniform(1003, 2, 2).bounds, 2)
+    assert first == 3
