@@ -52,6 +52,10 @@ SIGNATURES = {
                                 _vp, _i64, _i64, _vp, _sz, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cimrgp_layer_predict": (_i32, [_i32, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _dbl, _dbl, _vp, _i64, _i64, _vp, _sz,
                                     _vp, _i32, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "cimrgp_comm_unique_id": (_i32, [_vp]),
+    "cimrgp_comm_create": (_i32, [_i32, _i32, _vp, C.POINTER(_vp)]),
+    "cimrgp_comm_destroy": (_i32, [_vp]),
+    "cimrgp_allreduce_sum": (_i32, [_vp, _i32, _vp, _i64, _vp]),
     "cimrgp_set_rows_queues": (_i32, [_i32]),
     "cimrgp_get_rows_queues": (_i32, []),
     "cimrgp_tuning_build": (_i32, []),
@@ -98,6 +102,37 @@ def _shutdown():
             _lib.cimrgp_shutdown()
         except Exception:
             pass
+
+
+COMM_ID_BYTES = 128
+
+
+class Comm(object):
+    """The C ABI's communicator (include/cimrgp.h: cimrgp_comm_*), for callers without torch.distributed:
+    ``ident = Comm.unique_id()`` on one rank, shipped to the others by the caller; ``Comm(world, rank, ident)`` on
+    every rank (collective); ``allreduce_sum(tensor_or_ptr, ...)``; ``close()``."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        check(load().cimrgp_comm_unique_id(C.cast(buf, _vp)), "cimrgp_comm_unique_id")
+        return buf.raw
+
+    def __init__(self, world_size, rank, ident):
+        if len(ident) != COMM_ID_BYTES:
+            raise ValueError("a communicator id is %d bytes" % COMM_ID_BYTES)
+        self._h = _vp()
+        buf = C.create_string_buffer(bytes(ident), COMM_ID_BYTES)
+        check(load().cimrgp_comm_create(int(world_size), int(rank), C.cast(buf, _vp), C.byref(self._h)), "cimrgp_comm_create")
+        self.world_size, self.rank = int(world_size), int(rank)
+
+    def allreduce_sum(self, dtype, ptr, count, stream=None):
+        check(load().cimrgp_allreduce_sum(self._h, int(dtype), ptr, int(count), stream), "cimrgp_allreduce_sum")
+
+    def close(self):
+        if self._h:
+            check(load().cimrgp_comm_destroy(self._h), "cimrgp_comm_destroy")
+            self._h = _vp()
 
 
 def set_rows_queues(queues):

@@ -300,6 +300,25 @@ int cimrgp_layer_predict(int dtype, const void* x_dev, const int64_t* starts_dev
                          int64_t ldw, int64_t w_stride, void* mean_dev, void* var_dev,
                          void* stream);
 
+/* ---- the path's collective ------------------------------------
+ * The blocks of a resolution are independent and shard over the GPUs of a node, one process per GPU; what is
+ * exchanged is a SUM: at prediction the per-resolution predictions the reference adds up in a Python loop
+ * (src/MRGP.py:802-803; variance :902-905) -- every rank accumulates its blocks into a zero-initialised fused
+ * [mean | var] buffer and ONE in-place sum over the ranks finishes it -- and during the fit the training-point
+ * predictions of the layers coarser than the first one with a region per rank (src/Stats.py:126-157).
+ * RCCL over xGMI (ncclAllReduce, sum), loaded at first use (dlopen of librccl.so.1): the library has no link-time
+ * dependency on it.  Bootstrap as in RCCL: ONE rank calls cimrgp_comm_unique_id (CIMRGP_COMM_ID_BYTES bytes of HOST
+ * memory) and hands the bytes to the others through any channel the caller has (a file, MPI, torch.distributed's
+ * store ...); then EVERY rank calls cimrgp_comm_create(world_size, rank, id, &comm) with its HIP device current
+ * (collective: returns when all ranks have called it).  cimrgp_allreduce_sum enqueues the in-place sum of `count`
+ * elements of `dtype` on `stream` (every rank, same count, same order of calls).  A communicator is used by one
+ * thread at a time.  0 = ok; <0 = error (cimrgp_last_error; RCCL's message included). */
+#define CIMRGP_COMM_ID_BYTES 128
+int cimrgp_comm_unique_id(void* id_out_host);
+int cimrgp_comm_create(int world_size, int rank, const void* id_host, void** comm_out);
+int cimrgp_comm_destroy(void* comm);
+int cimrgp_allreduce_sum(void* comm, int dtype, void* buf_dev, int64_t count, void* stream);
+
 /* ---- process-level policy (no reference counterpart: the reference is one
  * process, src/MRGP.py has no streams) --------------------------------------
  * cimrgp_set_rows_queues: how many low-priority queues cimrgp_potrf_rows may

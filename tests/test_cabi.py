@@ -80,3 +80,19 @@ def test_schedule_watchdog_is_not_reported_as_not_positive_definite():
     # the flag crosses ranks inside a floating-point all-reduce (MRGP._fit): float32 rounds 2^31 - 1 up, sums grow
     assert dev.is_watchdog(np.float32(dev.INFO_WATCHDOG)) and dev.is_watchdog(float(dev.INFO_WATCHDOG) + 4096.0)
     assert not dev.is_watchdog(0) and not dev.is_watchdog(8 * 262144)
+
+
+def test_collective_entry_points_validate_their_arguments():
+    """cimrgp_comm_* / cimrgp_allreduce_sum (include/cimrgp.h): argument errors are reported before RCCL is touched
+    (no GPU here; the reduce itself runs in tests/test_gpu_configs.py with a world of one)."""
+    lib = _lib.load()
+    assert lib.cimrgp_comm_unique_id(None) < 0 and "null pointer" in _lib.last_error()
+    h = ctypes.c_void_p()
+    ident = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
+    assert lib.cimrgp_comm_create(2, 2, ctypes.cast(ident, ctypes.c_void_p), ctypes.byref(h)) < 0
+    assert "rank" in _lib.last_error()
+    assert lib.cimrgp_comm_create(1, 0, None, ctypes.byref(h)) < 0 and "null pointer" in _lib.last_error()
+    assert lib.cimrgp_allreduce_sum(None, _lib.F64, None, 4, None) < 0 and "communicator" in _lib.last_error()
+    assert lib.cimrgp_comm_destroy(None) < 0
+    with pytest.raises(ValueError):
+        _lib.Comm(1, 0, b"short")

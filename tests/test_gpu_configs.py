@@ -351,6 +351,36 @@ def test_bench_step_under_rccl_world_of_one():
     assert "cimrgp_block_posterior" in plain["step_is"]
 
 
+def test_c_abi_collective_world_of_one(ca):
+    """The boundary's own collective (include/cimrgp.h: cimrgp_comm_unique_id / cimrgp_comm_create /
+    cimrgp_allreduce_sum), ctypes only, no torch.distributed: a world of one on this GPU reduces the fused
+    [mean | var] buffer of a block's posterior in place -- the sum over one rank is the buffer itself -- in both
+    precisions, stream-ordered behind the kernels that fill it."""
+    from cimrgp_amd import _lib
+    dev = ca.device
+    comm = _lib.Comm(1, 0, _lib.Comm.unique_id())
+    try:
+        for tdt, code in ((torch.float64, _lib.F64), (torch.float32, _lib.F32)):
+            n, ns, q = 700, 130, 2
+            x, y = workloads.make_block(n, q)
+            xs = workloads.block_test_points(ns)
+            xd, yd, xsd = (dev.to_device(a, tdt, "cuda") for a in (x, y, xs))
+            kbuf, wbuf = dev.alloc_matrix(n, n, tdt, "cuda"), dev.alloc_matrix(ns + q, n, tdt, "cuda")
+            ws = dev.potrf_workspace(n, tdt, "cuda")
+            info = torch.zeros(1, dtype=torch.int32, device="cuda")
+            fused = torch.zeros(ns * (q + 1), dtype=tdt, device="cuda")
+            mean, var = fused[:ns * q].view(ns, q), fused[ns * q:]
+            alpha, z = torch.empty((n, q), dtype=tdt, device="cuda"), torch.empty((n, q), dtype=tdt, device="cuda")
+            dev.block_posterior(xd, yd, xsd, 0.3, 1.0, 0.05, kbuf, wbuf, ws, info, alpha, z, mean, var)
+            before = fused.clone()
+            comm.allreduce_sum(code, fused.data_ptr(), fused.numel(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert int(info.item()) == 0
+            assert torch.equal(fused, before) and bool(torch.isfinite(fused).all())
+    finally:
+        comm.close()
+
+
 def test_non_pd_block_raises_on_every_rank(ca, tmp_path):
     g0, g1 = _spawn("nonpd", tmp_path)
     assert g0["owner"].tolist() == [0, 1]

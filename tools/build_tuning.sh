@@ -9,7 +9,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DC
 mkdir -p tuning_obj
 pids=()
 OBJS=()
-for f in api gemm_nt potrf gram solve misc reduced layer; do
+for f in api gemm_nt potrf gram solve misc reduced layer comm; do
     if [ ! -f "tuning_obj/$f.o" ] || [ "$f.hip" -nt "tuning_obj/$f.o" ] || [ common.hpp -nt "tuning_obj/$f.o" ] || [ gemm_tile.hpp -nt "tuning_obj/$f.o" ] || [ ../../include/cimrgp.h -nt "tuning_obj/$f.o" ]; then
         $HIPCC $FLAGS -c "$f.hip" -o "tuning_obj/$f.o" &
         pids+=($!)
@@ -17,5 +17,5 @@ for f in api gemm_nt potrf gram solve misc reduced layer; do
     OBJS+=("tuning_obj/$f.o")
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libcimrgp_tuning.so "${OBJS[@]}"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libcimrgp_tuning.so "${OBJS[@]}" -ldl
 echo "built $(cd .. && pwd)/libcimrgp_tuning.so"
