@@ -39,6 +39,7 @@ const Knobs& knobs()
         v.far_pair_above = num("CIMRGP_FAR_PAIR", v.far_pair_above);
         v.fused_head0 = (int)num("CIMRGP_HEAD0", v.fused_head0);
         v.gemm_pers = (int)num("CIMRGP_GEMM_PERS", v.gemm_pers);
+        v.gemm_pers_f32 = (int)num("CIMRGP_GEMM_PERS_F32", v.gemm_pers_f32);
         v.pers_min_tiles = (int)num("CIMRGP_PERS_MIN_TILES", v.pers_min_tiles);
         v.chain_cus = (int)num("CIMRGP_CHAIN_CUS", v.chain_cus);
         v.rows_fused_tail = (int)num("CIMRGP_ROWS_FUSED", v.rows_fused_tail);

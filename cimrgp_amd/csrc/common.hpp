@@ -113,6 +113,7 @@ struct Knobs {
     int64_t far_pair_above = 8192;         // CIMRGP_FAR_PAIR: far part updated once per group of panels above this
     int fused_head0 = 1;                   // CIMRGP_HEAD0: first diagonal block of a panel takes its head update itself
     int gemm_pers = 256;                   // CIMRGP_GEMM_PERS: persistent trailing update on at most this many compute units (0: off)
+    int gemm_pers_f32 = 0;                 // CIMRGP_GEMM_PERS_F32: the persistent update for FP32 too (8-stage passes; built and bit-checked in round 4, not faster than the tile kernel: 3.85 against 3.64 ms for potrf n = 8192, 16.5 against 16.3 at 16 384)
     int pers_min_tiles = 512;              // CIMRGP_PERS_MIN_TILES: 128-tiles below which the tile-per-workgroup kernel is used
     int rows_fused_tail = 0;               // CIMRGP_ROWS_FUSED: carried rows catch up at the tail switch, then ride in the chain's launches
     int64_t rows_pair_above = 8192;        // CIMRGP_ROWS_PAIR: the carried rows' far updates take two panels at a time (K = 512) while more columns remain

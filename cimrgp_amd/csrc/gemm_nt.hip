@@ -176,18 +176,22 @@ static __device__ __forceinline__ int pers_tile_number(int w, int i, int grid, i
 constexpr int PERS_THREADS = 512;
 constexpr int PERS_STAGES = 16;
 
-template <typename T, bool LOWER>
+// NKT = K stages of 128 bytes per pass: 16 for K = 256 doubles (or 512 floats), 8 for K = 256 floats (round 4: the
+// FP32 form of one panel -- a stage is the same 128 bytes and the same matrix-core time in both precisions, so an
+// FP32 pass is half as long and carries the tile's sixteen C events two per stage).
+template <typename T, bool LOWER, int NKT>
 __global__ __launch_bounds__(PERS_THREADS)
 void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int64_t lda,
                     const T* __restrict__ B, int64_t ldb, int tiles_m, int tiles_n, int ntiles, int heads, int* __restrict__ flag)
 {
+    static_assert(NKT == 16 || NKT == 8, "sixteen C events per tile: one or two per K stage");
+    constexpr int EVS = 16 / NKT;                            // C events per stage
     using X = Mx<T>;
     using acc_t = typename X::acc_t;
     constexpr int BKE = KT_BYTES / (int)sizeof(T);
     constexpr int GT = 128;
     constexpr int OP_BYTES = GT * LROW;
     constexpr int RS = (sizeof(T) == 8) ? 4 : 1;             // crow(lane, r) = crow(lane, 0) + RS r
-    constexpr int NKT = PERS_STAGES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * OP_BYTES];       // 2 stages x 2 operands
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -313,13 +317,12 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
     // One tile: `cur` holds its C (requested during the previous pass), `oth` the finished previous
     // tile, which is stored and replaced by the next tile's C as the K loop proceeds.  The ring position
     // of a stage is its number's parity (16 stages per tile).
-#define PERS_EVENT_BLOCK(oth_)                                                                             \
-        if (PERS_EXP != 3) {                    /* event kt */                                                  \
-                constexpr int EM = 0;  (void)EM;                                                                \
-                const int mi_ = kt >> 2, ne_ = (kt >> 1) & 1, r0_ = 2 * (kt & 1);                               \
-                if (kt >= 2) {                      /* the values requested two events ago have arrived */      \
-                    oth_[(kt - 2) >> 2][((kt - 2) >> 1) & 1][2 * ((kt - 2) & 1)] = tld[kt & 1][0];              \
-                    oth_[(kt - 2) >> 2][((kt - 2) >> 1) & 1][2 * ((kt - 2) & 1) + 1] = tld[kt & 1][1];          \
+#define PERS_EVENT_ONE(oth_, e_)                                                                         \
+        if (PERS_EXP != 3) {                    /* event e_ (compile-time after unrolling) */                   \
+                const int mi_ = (e_) >> 2, ne_ = ((e_) >> 1) & 1, r0_ = 2 * ((e_) & 1);                         \
+                if ((e_) >= 2) {                    /* the values requested two events ago have arrived */      \
+                    oth_[((e_) - 2) >> 2][(((e_) - 2) >> 1) & 1][2 * (((e_) - 2) & 1)] = tld[(e_) & 1][0];      \
+                    oth_[((e_) - 2) >> 2][(((e_) - 2) >> 1) & 1][2 * (((e_) - 2) & 1) + 1] = tld[(e_) & 1][1];  \
                 }                                                                                               \
                 const int64_t uo_ = (int64_t)(mi_ * 16 + RS * r0_) * ldc + ne_ * 16;                            \
                 T* sb_ = c_prv + uo_;                                                                           \
@@ -329,10 +332,13 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
                 }                                                                                               \
                 const T* lb_ = (PERS_EXP == 6) ? c_nxt : c_nxt + uo_;                                           \
                 if (PERS_EXP != 5) {                                                                            \
-                    tld[kt & 1][0] = lb_[coff];                                                                 \
-                    tld[kt & 1][1] = (lb_ + (int64_t)RS * ldc)[coff];                                           \
+                    tld[(e_) & 1][0] = lb_[coff];                                                               \
+                    tld[(e_) & 1][1] = (lb_ + (int64_t)RS * ldc)[coff];                                         \
                 }                                                                                               \
             }
+    /* the stage's events: one (NKT = 16) or two (NKT = 8) */
+#define PERS_EVENT_BLOCK(oth_)                                                                                  \
+        { _Pragma("unroll") for (int ev_ = 0; ev_ < EVS; ++ev_) { PERS_EVENT_ONE(oth_, kt * EVS + ev_) } }
 #define PERS_PASS(cur_, oth_)                                                                                   \
     {                                                                                                           \
         const int tn_ = pers_tile_number(wg, it + 1, grid, ntiles);                                             \
@@ -388,6 +394,7 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
     }
 #undef PERS_PASS
 #undef PERS_EVENT_BLOCK
+#undef PERS_EVENT_ONE
 #undef PERS_INTERLEAVE
 #undef PERS_MMA
 #undef PERS_MMA_NF
@@ -423,7 +430,8 @@ static int gemm_launch(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, i
 int gemm_pers_head_tiles(int64_t m, int k, int elem_bytes)
 {
     const int bke = KT_BYTES / elem_bytes;
-    if (elem_bytes != 8 || knobs().gemm_pers < 8 || m % 128 != 0 || m / 128 < 3 || k % bke != 0 || k / bke != PERS_STAGES) return 0;
+    const int pers_nkt = (elem_bytes == 8) ? PERS_STAGES : PERS_STAGES / 2;
+    if (knobs().gemm_pers < 8 || (elem_bytes != 8 && !knobs().gemm_pers_f32) || m % 128 != 0 || m / 128 < 3 || k % bke != 0 || k / bke != pers_nkt) return 0;
     return (int)(2 * (m / 128) - 2);
 }
 
@@ -460,9 +468,11 @@ int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t 
         constexpr int bke = KT_BYTES / (int)sizeof(T);
         const int want = (bt.pers >= 0) ? bt.pers : knobs().gemm_pers;
         const int nkt = (k % bke) ? 0 : k / bke;
-        // (FP64 only: an FP32 pass is K = 512 -- paired panels -- and runs at twice the matrix rate over the same C
-        // traffic per tile; measured slower than the tile kernel, whole potrf at n = 16 384: 18.6 against 17.1 ms)
-        if (sizeof(T) == 8 && want >= 8 && nkt == PERS_STAGES && bt.count == 1 && !bt.skip_first && m % 128 == 0 && n % 128 == 0 &&
+        // one panel in either precision: 16 stages of doubles, 8 of floats.  The FP32 form is off by default
+        // (knobs().gemm_pers_f32): stand-alone it equals the tile kernel (0.52-0.58 of the FP32 peak both), inside the
+        // factorisation it is slower (3.85 against 3.64 ms at n = 8192): HISTORY.md, round 4.
+        constexpr int pers_nkt = (sizeof(T) == 8) ? PERS_STAGES : PERS_STAGES / 2;
+        if (want >= 8 && (sizeof(T) == 8 || knobs().gemm_pers_f32) && nkt == pers_nkt && bt.count == 1 && !bt.skip_first && m % 128 == 0 && n % 128 == 0 &&
             ldc < (1ll << 23) && lda < (1ll << 23) && ldb < (1ll << 23) && (t128 >= knobs().pers_min_tiles || bt.head_first || bt.pers_force)) {
             const int64_t tm = m / 128, tn = n / 128;
             // head-first launch (the look-ahead's combined head + bulk update): tile (0, 0) is left to the chain
@@ -476,7 +486,7 @@ int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t 
             if (g8 > cus) g8 = cus;
             const dim3 grid((unsigned)g8);
 #define CIMRGP_PERS_LAUNCH(LOW_) \
-            hipLaunchKernelGGL((k_gemm_nt_pers<T, LOW_>), grid, dim3(PERS_THREADS), 0, st, c, ldc, a, lda, b, ldb, (int)tm, (int)tn, (int)tiles, heads, bt.flag)
+            hipLaunchKernelGGL((k_gemm_nt_pers<T, LOW_, pers_nkt>), grid, dim3(PERS_THREADS), 0, st, c, ldc, a, lda, b, ldb, (int)tm, (int)tn, (int)tiles, heads, bt.flag)
             if (lower) CIMRGP_PERS_LAUNCH(true); else CIMRGP_PERS_LAUNCH(false);
 #undef CIMRGP_PERS_LAUNCH
             CIMRGP_LAUNCH_CHECK(fn);

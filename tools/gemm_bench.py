@@ -16,12 +16,15 @@ ap.add_argument("--m", default="7936")
 ap.add_argument("--k", type=int, default=256)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--check", action="store_true")
+ap.add_argument("--dtype", default="f64")
 args = ap.parse_args()
 dev.require_gpu()
+tdt = dev.as_torch_dtype(args.dtype)
+peak = 78.6 if tdt == torch.float64 else 157.3
 for m in [int(v) for v in args.m.split(",")]:
     k = args.k
-    c = dev.alloc_matrix(m, m, torch.float64, "cuda")
-    a = dev.alloc_matrix(m, k, torch.float64, "cuda")
+    c = dev.alloc_matrix(m, m, tdt, "cuda")
+    a = dev.alloc_matrix(m, k, tdt, "cuda")
     torch.manual_seed(0)
     c.normal_()
     a.normal_()
@@ -42,7 +45,7 @@ for m in [int(v) for v in args.m.split(",")]:
             times.append(e0.elapsed_time(e1))
     med = float(np.median(times))
     rec = dict(m=m, k=k, us=round(med * 1e3, 1), tflops=round(m * (m + 1.0) * k / med / 1e9, 2),
-               frac=round(m * (m + 1.0) * k / med / 1e9 / 78.6, 3))
+               frac=round(m * (m + 1.0) * k / med / 1e9 / peak, 3), dtype=args.dtype)
     if args.check:
         rec.update(rel_err=err, far_upper_untouched=upper_untouched)
     print(json.dumps(rec), flush=True)
