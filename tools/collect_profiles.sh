@@ -1,10 +1,10 @@
 #!/bin/bash
 # Collect the judged profiles of the N = 8192 bench on the GPU box (run from the repo root):
-#   bash tools/collect_profiles.sh r03 [part ...]     parts: bench stats timelines pmc sweep configs rccl variants (default: all)
+#   bash tools/collect_profiles.sh r04 [part ...]     parts: bench stats timelines pmc sweep configs rccl variants config5 chain (default: all but config5)
 # -> gpurun_out/r03_*; then locally:  python3 tools/finalize_profiles.py r03   (copies what is kept into profiles/,
 # stamps the commit).  rocprofv3: counters in their own passes with --kernel-trace only; the program itself after `--`.
 tag=${1:-rXX}; shift || true
-parts=${*:-"bench stats timelines pmc sweep configs rccl variants"}
+parts=${*:-"bench stats timelines pmc sweep configs rccl variants chain"}
 out=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 want() { case " $parts " in *" $1 "*) return 0;; esac; return 1; }
@@ -57,8 +57,23 @@ if want rccl; then
         python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline $mode 2>/dev/null | tail -1
     done > $out/${tag}_rccl_world_of_one.jsonl
 fi
+if want config5; then
+    # BASELINE configs[4]: FP32 vs FP64 at n = 16384 -- info, errors against the CPU oracle, timings (several minutes of host BLAS) ...
+    python3 tools/precision_sweep.py > $out/${tag}_config5_fp32_vs_fp64_n16384.jsonl 2> $out/${tag}_config5.err || tail -5 $out/${tag}_config5.err
+    # ... and the matrix-core counters of one factorisation in each precision
+    for dt in f64 f32; do
+        rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv \
+            -d $out/${tag}_c5pmc_$dt -- python3 tools/potrf_once.py 16384 2 0 $dt > /dev/null 2> $out/${tag}_c5pmc_$dt.err || { tail -5 $out/${tag}_c5pmc_$dt.err; exit 1; }
+        python3 tools/pmc_summary.py $out/${tag}_c5pmc_$dt/ > $out/${tag}_config5_mfma_counters_$dt.json
+        rm -rf $out/${tag}_c5pmc_$dt
+    done
+fi
+if want chain && [ -x tools/diag_probe_e0 ]; then
+    # the chain kernels stand-alone: both forms agree bit for bit, are repeatable (also beside a running FP32 update), launch rates
+    timeout -k 10 600 tools/diag_probe_e0 | grep -v "^raw\|nine waves):\|^row\|kprev 192" > $out/${tag}_chain_kernels.txt
+fi
 if want variants && [ -f cimrgp_amd/libcimrgp_tuning_e1.so ]; then
-    # timing-only builds of the persistent kernel (built beforehand: bash tools/exp_variants.sh build)
-    bash tools/exp_variants.sh > $out/${tag}_pers_variants.txt 2>&1
+    # timing-only builds of the persistent kernel (built beforehand: bash tools/lab/exp_variants.sh build)
+    bash tools/lab/exp_variants.sh > $out/${tag}_pers_variants.txt 2>&1
 fi
 echo collected

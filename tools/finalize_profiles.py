@@ -21,7 +21,8 @@ commit = subprocess.run(["git", "-C", root, "rev-parse", "HEAD"], capture_output
 dirty = subprocess.run(["git", "-C", root, "status", "--porcelain", "cimrgp_amd/csrc"], capture_output=True, text=True).stdout.strip()
 keep = ["bench_n8192.json", "bench_n8192_under_rocprof.json", "bench_n8192_kernel_stats.csv", "timeline_n8192.txt",
         "timeline_n8192_rows.txt", "pmc_raw.json", "pmc_bench_n8192.json", "potrf_sweep.jsonl", "gemm_standalone.jsonl", "gemm_standalone_tile_kernel.jsonl", "pers_variants.txt", "layer_times.jsonl",
-        "config3_n65536.json", "config4_n262144_one_gpu.json", "config4_n8192_two_ranks_gloo.json", "rccl_world_of_one.jsonl"]
+        "config3_n65536.json", "config4_n262144_one_gpu.json", "config4_n8192_two_ranks_gloo.json", "rccl_world_of_one.jsonl", "config5_fp32_vs_fp64_n16384.jsonl", "config5_mfma_counters_f64.json", "config5_mfma_counters_f32.json",
+        "chain_kernels.txt"]
 for name in keep:
     src = os.path.join(root, "gpurun_out", "%s_%s" % (tag, name))
     if not os.path.exists(src) or os.path.getsize(src) == 0:

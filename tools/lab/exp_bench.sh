@@ -1,7 +1,7 @@
 #!/bin/bash
 # the N = 8192 step (with carried rows) under schedule knobs: tuning library
 set -uo pipefail
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 OUT=gpurun_out; TAG=${1:-x}
 export CIMRGP_LIB_PATH=$PWD/cimrgp_amd/libcimrgp_tuning.so
 L=$OUT/${TAG}_benchknobs.log; : > $L

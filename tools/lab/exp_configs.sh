@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 export CIMRGP_LIB_PATH=$PWD/cimrgp_amd/libcimrgp_tuning.so
 for fm in 0 768 100000000; do
   for c in 3 4; do

@@ -1,6 +1,6 @@
 #!/bin/bash
 set -uo pipefail
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 OUT=gpurun_out; TAG=${1:-x}
 timeout -k 10 900 python3 -m pytest tests/test_gpu_kernels.py tests/test_gpu_layer.py -x -q -m gpu > $OUT/${TAG}_tests.log 2>&1 || { tail -40 $OUT/${TAG}_tests.log; echo TESTS FAILED; exit 1; }
 tail -2 $OUT/${TAG}_tests.log

@@ -1,7 +1,7 @@
 #!/bin/bash
 # stand-alone trailing-update rate, old kernel against the persistent one, then whole potrf with the split
 set -uo pipefail
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 OUT=gpurun_out; mkdir -p $OUT
 TAG=${1:-x}
 export CIMRGP_LIB_PATH=$PWD/cimrgp_amd/libcimrgp_tuning.so

@@ -1,7 +1,7 @@
 #!/bin/bash
 # whole potrf at several sizes under schedule knobs (tuning library): CFGS = one env assignment list per line
 set -uo pipefail
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 export CIMRGP_LIB_PATH=$PWD/cimrgp_amd/libcimrgp_tuning.so
 SIZES=${SIZES:-"8192"}
 while read -r cfg; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 3, experiment A: the persistent trailing-update kernel stand-alone and inside potrf.
 set -uo pipefail
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 OUT=gpurun_out; mkdir -p $OUT
 export CIMRGP_LIB_PATH=$PWD/cimrgp_amd/libcimrgp_tuning.so
 L=$OUT/r03a_gemm.log; : > $L

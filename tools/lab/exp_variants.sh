@@ -1,7 +1,7 @@
 #!/bin/bash
 # timing-only variants of the persistent kernel (libcimrgp_tuning_eN.so: wrong results by construction)
-cd "$(dirname "$0")/.."
-# build the variants first (on the CPU box, before gpurun):  bash tools/exp_variants.sh build
+cd "$(dirname "$0")/../.."
+# build the variants first (on the CPU box, before gpurun):  bash tools/lab/exp_variants.sh build
 if [ "$1" = build ]; then
   bash tools/build_tuning.sh
   cd cimrgp_amd/csrc

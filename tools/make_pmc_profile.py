@@ -62,13 +62,25 @@ def main():
     if mf:
         r = raw[mf]
         per_xcd = r["GRBM_GUI_ACTIVE"]["mean"] / 8.0
+        # the clock the part sustains while this kernel runs: GPU-clock cycles of the launch (GRBM_GUI_ACTIVE per XCD)
+        # over its duration in the kernel trace of the same command
+        pers_stat = next((v for k, v in stats.items() if "k_gemm_nt_pers<double, true" in k), None)
+        if pers_stat and "pers" in mf:
+            clock_ghz = per_xcd / (pers_stat["avg_us"] * 1e3)
+            out["sustained_clock"] = dict(
+                kernel=mf, GRBM_GUI_ACTIVE_per_xcd=per_xcd, avg_kernel_us=pers_stat["avg_us"], clock_ghz=clock_ghz,
+                fp64_mfma_peak_at_that_clock_tflops=78.6 * clock_ghz / 2.4,
+                note="78.6 TFLOP/s is quoted at 2.4 GHz; under FP64 matrix load the part runs slower, and no kernel can beat "
+                     "the peak at the clock it is given")
         out["trailing_update_mfma"] = dict(
             kernel=mf, launches=r["SQ_VALU_MFMA_BUSY_CYCLES"]["launches"], SQ_VALU_MFMA_BUSY_CYCLES=r["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"],
             GRBM_GUI_ACTIVE_per_xcd=per_xcd, SQ_INSTS_VALU_MFMA_MOPS_F64=r["SQ_INSTS_VALU_MFMA_MOPS_F64"]["mean"],
             mfma_busy_frac=r["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (per_xcd * 1024.0),
             mfma_flops_per_launch=r["SQ_INSTS_VALU_MFMA_MOPS_F64"]["mean"] * 512.0,
             note="SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs), GRBM_GUI_ACTIVE / 8 (reported summed over the 8 XCDs): the "
-                 "fraction of ALL the chip's matrix pipes' cycles (the kernel runs on 256 - chain_cus compute units)")
+                 "fraction of ALL the chip's matrix pipes' cycles (the kernel runs on 256 - chain_cus compute units).  NOT an "
+                 "independent utilisation measurement: the counter equals issued matrix flops / 32 per SIMD-cycle exactly, so this "
+                 "is achieved flops / (clock x peak flops per clock) -- the same number as frac_of_sustained_peak")
     print(json.dumps(out, indent=1))
 
 

@@ -18,7 +18,7 @@ def family(name):
     m = re.search(r"k_gemm_nt_sub<(\w+), (true|false), (\d)>", name)
     if m:
         return "k_gemm_nt_sub<%s,%s,%s-tile>" % (m.group(1), "lower" if m.group(2) == "true" else "rect", 32 * int(m.group(3)))
-    m = re.search(r"k_gemm_nt_pers<(\w+), (true|false)>", name)
+    m = re.search(r"k_gemm_nt_pers<(\w+), (true|false)(?:, \d+)?>", name)
     if m:
         return "k_gemm_nt_pers<%s,%s>" % (m.group(1), "lower" if m.group(2) == "true" else "rect")
     m = re.search(r"k_rbf_gram<(\w+), (true|false), (\d)>", name)

@@ -14,15 +14,16 @@ from cimrgp_amd import device as dev
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 rows = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+tdt = torch.float32 if (len(sys.argv) > 4 and sys.argv[4] == "f32") else torch.float64
 dev.require_gpu()
 rng = np.random.default_rng(0)
-x = torch.as_tensor(np.sort(rng.uniform(-1.7, 1.7, size=(n, 1)), axis=0)).cuda()
-xs = torch.as_tensor(np.sort(rng.uniform(-1.7, 1.7, size=(max(rows, 1), 1)), axis=0)).cuda()
+x = torch.as_tensor(np.sort(rng.uniform(-1.7, 1.7, size=(n, 1)), axis=0)).to("cuda", tdt)
+xs = torch.as_tensor(np.sort(rng.uniform(-1.7, 1.7, size=(max(rows, 1), 1)), axis=0)).to("cuda", tdt)
 for _ in range(reps):
     k = dev.rbf_gram(x, 0.1, 1.0, 0.01, lower_only=True)
     torch.cuda.synchronize()
     if rows:
-        w = dev.alloc_matrix(rows, n, torch.float64, "cuda")
+        w = dev.alloc_matrix(rows, n, tdt, "cuda")
         dev.rbf_cross(xs, x, 0.1, 1.0, out=w)
         torch.cuda.synchronize()
         dev.potrf_rows(k, n, w, rows)
