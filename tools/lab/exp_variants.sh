@@ -5,11 +5,11 @@ cd "$(dirname "$0")/../.."
 if [ "$1" = build ]; then
   bash tools/build_tuning.sh
   cd cimrgp_amd/csrc
-  for e in 1 2 3 4 5 6 7 8; do
+  for e in 1 2 3 4 5 6 7 8 9 10 11; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DCIMRGP_TUNING -DPERS_EXP=$e \
       -c gemm_nt.hip -o tuning_obj/gemm_nt_e$e.o
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libcimrgp_tuning_e$e.so tuning_obj/api.o tuning_obj/gemm_nt_e$e.o \
-      tuning_obj/potrf.o tuning_obj/gram.o tuning_obj/solve.o tuning_obj/misc.o tuning_obj/reduced.o tuning_obj/layer.o
+      tuning_obj/potrf.o tuning_obj/gram.o tuning_obj/solve.o tuning_obj/misc.o tuning_obj/reduced.o tuning_obj/layer.o tuning_obj/comm.o -ldl
   done
   exit 0
 fi
