@@ -47,6 +47,7 @@ const Knobs& knobs()
         v.fused_max_chain_wgs = num("CIMRGP_FUSED_MAX", v.fused_max_chain_wgs);
         v.batch_halves_min = (int)num("CIMRGP_BATCH_HALVES", v.batch_halves_min);
         v.rows_cus = (int)num("CIMRGP_ROWS_CUS", v.rows_cus);
+        v.rows_step = (int)num("CIMRGP_ROWS_STEP", v.rows_step);
         v.trsm_group = (int)num("CIMRGP_TRSM_GROUP", v.trsm_group);
         v.rows_beside_tail_below = num("CIMRGP_ROWS_BESIDE", v.rows_beside_tail_below);
         v.tail_far_cus = (int)num("CIMRGP_TAIL_FAR_CUS", v.tail_far_cus);

@@ -119,7 +119,8 @@ struct Knobs {
     int64_t rows_pair_above = 8192;        // CIMRGP_ROWS_PAIR: the carried rows' far updates take two panels at a time (K = 512) while more columns remain
     int64_t fused_max_chain_wgs = 768;     // CIMRGP_FUSED_MAX: one-queue sweeps ride their updates in the chain's launches while batch x n / 32 is at most this
     int batch_halves_min = 8;              // CIMRGP_BATCH_HALVES: a batched factorisation of at least this many blocks (that does not ride) runs as two halves on two queues
-    int rows_cus = 192;                    // CIMRGP_ROWS_CUS: compute units of the carried rows' far updates (persistent kernel; 0: tile-per-workgroup kernel)
+    int rows_step = 1;                     // CIMRGP_ROWS_STEP: carried rows' chain as one launch per panel (k_rows_step: previous panel's update + 256-wide solve; 0: update and k_trsm256 as two launches)
+    int rows_cus = 224;                    // CIMRGP_ROWS_CUS: compute units of the carried rows' far updates (persistent kernel; 0: tile-per-workgroup kernel)
     int trsm_group = 1;                    // CIMRGP_TRSM_GROUP: batched launches solve 4 row tiles per workgroup (0: one)
     int64_t rows_beside_tail_below = 2560; // CIMRGP_ROWS_BESIDE: with carried rows, the factorisation's tail (trailing matrix at most this) is the one-queue fused sweep while the rows keep their own queues (0: look-ahead to the end)
     int tail_far_cus = 160;                // CIMRGP_TAIL_FAR_CUS: compute units of FAR(prev) on the second queue of the fused tail (0: always riders)

@@ -1532,6 +1532,193 @@ void k_trsm256(T* __restrict__ P, int64_t ldp, int M, int w, const T* __restrict
 }
 
 // ---------------------------------------------------------------------------
+// Round 4: ONE launch per panel for the carried rows' own chain.  Panel p of the rows needs
+//     W_p = (B_p - W_{p-1} L[p, p-1]^T) L_pp^-T
+// -- the update by the previous panel (everything older has been applied by the bulk "far" updates, which are
+// off this chain) and the 256-wide solve.  Until round 4 these were two launches of general kernels (a 64-tile
+// update of 132 workgroups, 38-65 us, then k_trsm256, 34-55 us: both latency-bound) and the rows fell eleven
+// panels behind a factorisation whose own chain takes 93-125 us per panel.  Here a workgroup owns 16 rows (one
+// MFMA row tile) for both parts:
+//   * wave w owns the four 16-column tiles  64 j + 16 w  (j = 0..3: one of every 64-column sub-block), so that in
+//     sub-step j all four waves work on sub-block j and each already holds its share of it;
+//   * the right operand (rows of L / of the 64 x 64 inverses) goes from global memory STRAIGHT into the
+//     matrix-core operand registers -- lane (n, q) takes 32 contiguous bytes of row n per 128-byte chunk of K
+//     (the k order inside a chunk is a permutation, the same one on both operands), so a wave's request is 16
+//     rows x 128 bytes, whole cache lines, and nobody waits at a barrier for a staging buffer; the loads run a
+//     ring of chunks ahead of the multiplies, through the barriers (LDS-scoped fences: a __syncthreads() would
+//     drain them);
+//   * the left operands (W_{p-1}'s rows, the solved sub-blocks, the 16 x 64 sub-block being solved) live in LDS.
+// Sub-step j: T_j = B_j - W_{p-1} L[j, p-1]^T (phase 1, all j at once) - sum_{i<j} W_i L[j, i]^T, then
+// W_j = T_j inv_j^T through LDS (two barriers per sub-step).  Full panels only (w = 256, previous panel 256 or
+// none); ragged last panels keep the two-launch form.
+// ---------------------------------------------------------------------------
+template <typename T> struct RowsStep {
+    static constexpr int R = 16;                                   // rows per workgroup
+    static constexpr int CHE = 128 / (int)sizeof(T);               // elements per 128-byte chunk of K
+    static constexpr int NCP = CIMRGP_NB / CHE;                    // chunks of the previous panel: 16 (f64) / 8 (f32)
+    static constexpr int NCS = SB / CHE;                           // chunks of a 64-column sub-block: 4 / 2
+    static constexpr int LPE = 32 / (int)sizeof(T);                // elements a lane takes per chunk (32 bytes)
+    static constexpr int ASTR = CIMRGP_NB * (int)sizeof(T) + 16;   // LDS row strides: 16 bytes of padding
+    static constexpr int TSTR = SB * (int)sizeof(T) + 16;
+    static constexpr int BYTES = 2 * R * ASTR + R * TSTR;
+    static constexpr int RING1 = 3;                                // phase 1: chunks in flight (4 tiles each)
+    static constexpr int RING2 = 8;                                // phase 2: chunks in flight (1 tile each)
+    static constexpr int P2_TOTAL = NCS * (1 + 2 + 3 + 4);
+};
+
+template <typename T, bool HAS_PREV>
+__global__ __launch_bounds__(256)
+void k_rows_step(T* __restrict__ P, int64_t ldp, int M, const T* __restrict__ Lrow, int64_t ldl, const T* __restrict__ inv64)
+{
+    using X = Mx<T>;
+    using acc_t = typename X::acc_t;
+    using RS = RowsStep<T>;
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    constexpr int KPREV = HAS_PREV ? CIMRGP_NB : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[RS::BYTES];
+    unsigned char* aprev = smem;                       // W_{p-1}: R rows x 256
+    unsigned char* wcur  = smem + RS::R * RS::ASTR;    // W_p as it is solved
+    unsigned char* tbuf  = smem + 2 * RS::R * RS::ASTR;   // T_j: R rows x 64
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = (int)blockIdx.x * RS::R;
+    const int mrows = min(RS::R, M - row0);
+    T* Prow = P + (int64_t)row0 * ldp;                 // this workgroup's rows, first column of panel p
+    const int fn = lane & 15, fq = lane >> 4;
+    const int ctile = 16 * wave + fn;                  // this lane's column inside a 64-column sub-block
+
+    // W_{p-1}'s rows: requested first, written to LDS after everything else has been requested
+    v4u stg[HAS_PREV ? RS::NCP / 2 : 1];
+    const int sr = tid >> 4, st16 = tid & 15;
+    if (HAS_PREV) {
+        const T* src = Prow - KPREV + (int64_t)min(sr, mrows - 1) * ldp;    // rows past the end: a valid row's values, never stored
+#pragma unroll
+        for (int i = 0; i < RS::NCP / 2; ++i) stg[i] = *reinterpret_cast<const v4u*>(src + (i * 16 + st16) * X::EPC);
+    }
+    acc_t acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            acc[j][r] = Prow[(int64_t)min(X::crow(lane, r), mrows - 1) * ldp + SB * j + ctile];
+
+    // right-operand rows of this lane: rows SB j + ctile of the panel's row block of L, and of the inverses
+    const T* lp[4];
+    const T* ip[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        lp[j] = Lrow + (int64_t)(SB * j + ctile) * ldl + fq * RS::LPE;
+        ip[j] = inv64 + (int64_t)j * (SB * SB) + ctile * SB + fq * RS::LPE;
+    }
+    // phase 2's operand stream in the order it is consumed: sub-step j = j NCS chunks of L[j, 0 .. 64 j) (behind
+    // the previous panel's 256 columns), then NCS chunks of inv_j
+    auto p2_addr = [&](int p) -> const T* {
+        int j = 0, base = 0;
+#pragma unroll
+        for (j = 0; j < 4; ++j) {
+            const int len = (j + 1) * RS::NCS;
+            if (p < base + len) break;
+            base += len;
+        }
+        const int c = p - base;
+        return (c < j * RS::NCS) ? lp[j] + KPREV + c * RS::CHE : ip[j] + (c - j * RS::NCS) * RS::CHE;
+    };
+    v4u ring2[RS::RING2][2];
+#define ROWS_P2_LOAD(p_)                                                                   \
+    {                                                                                      \
+        const T* q_ = p2_addr(p_);                                                         \
+        ring2[(p_) % RS::RING2][0] = *reinterpret_cast<const v4u*>(q_);                    \
+        ring2[(p_) % RS::RING2][1] = *reinterpret_cast<const v4u*>(q_ + X::EPC);           \
+    }
+    // the four 8-byte k-slots of a lane's 32 bytes
+#define ROWS_SLOT(v_, s_) ((s_) == 0 ? make_uint2((v_)[0].x, (v_)[0].y) : (s_) == 1 ? make_uint2((v_)[0].z, (v_)[0].w) \
+                           : (s_) == 2 ? make_uint2((v_)[1].x, (v_)[1].y) : make_uint2((v_)[1].z, (v_)[1].w))
+
+    if (HAS_PREV) {
+        v4u ring1[RS::RING1][4][2];
+#define ROWS_P1_LOAD(c_)                                                                   \
+    {                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                    \
+            const T* q_ = lp[j] + (c_) * RS::CHE;                                          \
+            ring1[(c_) % RS::RING1][j][0] = *reinterpret_cast<const v4u*>(q_);             \
+            ring1[(c_) % RS::RING1][j][1] = *reinterpret_cast<const v4u*>(q_ + X::EPC);    \
+        }                                                                                  \
+    }
+#pragma unroll
+        for (int c = 0; c < RS::RING1; ++c) ROWS_P1_LOAD(c)
+#pragma unroll
+        for (int i = 0; i < RS::NCP / 2; ++i)
+            *reinterpret_cast<v4u*>(aprev + sr * RS::ASTR + (i * 16 + st16) * 16) = stg[i];
+        lds_barrier();                                                   // W_{p-1}'s rows are in LDS
+        const unsigned char* abase = aprev + fn * RS::ASTR + fq * 32;
+#pragma unroll
+        for (int c = 0; c < RS::NCP; ++c) {
+            v4u a[2];
+            a[0] = *reinterpret_cast<const v4u*>(abase + c * 128);
+            a[1] = *reinterpret_cast<const v4u*>(abase + c * 128 + 16);
+            if (c == RS::NCP - 1) {
+                // the ring drains: phase 2's first chunks take its place
+#pragma unroll
+                for (int p = 0; p < RS::RING2; ++p) ROWS_P2_LOAD(p)
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const uint2 an = X::neg(ROWS_SLOT(a, s));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = X::mma(an, ROWS_SLOT(ring1[c % RS::RING1][j], s), acc[j]);
+            }
+            if (c + RS::RING1 < RS::NCP) ROWS_P1_LOAD(c + RS::RING1)
+        }
+#undef ROWS_P1_LOAD
+    } else {
+#pragma unroll
+        for (int p = 0; p < RS::RING2; ++p) ROWS_P2_LOAD(p)
+    }
+
+    int pos = 0;                                       // position in phase 2's stream (a constant once unrolled)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // T_j's share of this wave: the solved sub-blocks 0 .. j-1 of this panel against L[j, 0 .. 64 j)
+        const unsigned char* wbase = wcur + fn * RS::ASTR + fq * 32;
+#pragma unroll
+        for (int c = 0; c < j * RS::NCS; ++c, ++pos) {
+            v4u a[2];
+            a[0] = *reinterpret_cast<const v4u*>(wbase + c * 128);
+            a[1] = *reinterpret_cast<const v4u*>(wbase + c * 128 + 16);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                acc[j] = X::mma(X::neg(ROWS_SLOT(a, s)), ROWS_SLOT(ring2[pos % RS::RING2], s), acc[j]);
+            if (pos + RS::RING2 < RS::P2_TOTAL) ROWS_P2_LOAD(pos + RS::RING2)
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<T*>(tbuf + X::crow(lane, r) * RS::TSTR + ctile * (int)sizeof(T)) = acc[j][r];
+        lds_barrier();                                                   // T_j complete
+        acc_t x = acc_zero<T>();
+        const unsigned char* tbase = tbuf + fn * RS::TSTR + fq * 32;
+#pragma unroll
+        for (int c = 0; c < RS::NCS; ++c, ++pos) {
+            v4u a[2];
+            a[0] = *reinterpret_cast<const v4u*>(tbase + c * 128);
+            a[1] = *reinterpret_cast<const v4u*>(tbase + c * 128 + 16);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                x = X::mma(ROWS_SLOT(a, s), ROWS_SLOT(ring2[pos % RS::RING2], s), x);
+            if (pos + RS::RING2 < RS::P2_TOTAL) ROWS_P2_LOAD(pos + RS::RING2)
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int lr = X::crow(lane, r);
+            if (j < 3) *reinterpret_cast<T*>(wcur + lr * RS::ASTR + (SB * j + ctile) * (int)sizeof(T)) = x[r];
+            if (lr < mrows) Prow[(int64_t)lr * ldp + SB * j + ctile] = x[r];
+        }
+        if (j < 3) lds_barrier();                                        // W_j is in LDS; T's buffer is free
+    }
+#undef ROWS_P2_LOAD
+#undef ROWS_SLOT
+}
+
+// ---------------------------------------------------------------------------
 // 256x256 inverses of the diagonal blocks, for the skinny solves: the identity is
 // carried through the panel solve, batched over ALL panels (blockIdx.y):
 // invT_p = I L_pp^-T = (L_pp^-1)^T  (upper triangular, row r = column r of L_pp^-1),
@@ -1618,6 +1805,7 @@ static inline int group_size(int64_t far, int64_t pair_above)
 struct PanelGroup {
     int64_t g0 = -1;      // first column of the group's first panel (-1: no group open)
     int left = 0;         // panels of the group still to come, this one included
+    bool near_pending = false;   // carried rows: the previous panel's update of THIS panel's columns is owed (k_rows_step applies it)
 };
 
 // The latency-bound chain of one panel [k0, k0 + w) on stream st: the first 64-column diagonal
@@ -1711,6 +1899,23 @@ static int panel_chain(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, int
 // (fewer passes over B): every panel of a group but the last only updates the next panel's
 // columns (with all the group's panels so far), the last one everything right of itself
 // (adjacent panels are adjacent columns of B and of L).
+// The rows' solve of one full panel [r0, r0 + 256): k_rows_step, with the previous panel's update of these columns
+// fused in (`with_prev`: the caller left it out of its updates) or as the solve alone.
+template <typename T>
+static int rows_step_launch(T* b, int64_t ldb, int64_t m, const T* lmat, int64_t ld, const T* ws, int64_t r0, bool with_prev,
+                            hipStream_t st, const char* fn)
+{
+    const dim3 grid((unsigned)((m + RowsStep<T>::R - 1) / RowsStep<T>::R));
+    if (with_prev)
+        hipLaunchKernelGGL((k_rows_step<T, true>), grid, dim3(256), 0, st, b + r0, ldb, (int)m,
+                           (const T*)(lmat + r0 * ld + (r0 - CIMRGP_NB)), ld, (const T*)(ws + (r0 / SB) * (SB * SB)));
+    else
+        hipLaunchKernelGGL((k_rows_step<T, false>), grid, dim3(256), 0, st, b + r0, ldb, (int)m,
+                           (const T*)(lmat + r0 * ld + r0), ld, (const T*)(ws + (r0 / SB) * (SB * SB)));
+    CIMRGP_LAUNCH_CHECK(fn);
+    return 0;
+}
+
 template <typename T>
 static int rows_panel_step(T* b, int64_t ldb, int64_t m, const T* lmat, int64_t ld, int64_t n, const T* ws,
                            int64_t r0, PanelGroup& grp, int64_t pair_above, hipStream_t st, const char* fn,
@@ -1719,10 +1924,22 @@ static int rows_panel_step(T* b, int64_t ldb, int64_t m, const T* lmat, int64_t 
     const int64_t rw = (n - r0 < CIMRGP_NB) ? (n - r0) : CIMRGP_NB;
     const int64_t r1 = r0 + rw;
     GemmBatch gb; gb.count = bt.count; gb.sc = gb.sa = bt.sb; gb.sb = bt.sk;
-    hipLaunchKernelGGL((k_trsm256<T>), dim3((unsigned)((m + TR - 1) / TR), (unsigned)bt.count), dim3(256), 0, st,
-                       b + r0, ldb, (int)m, (int)rw, (const T*)(lmat + r0 * ld + r0), ld,
-                       (const T*)(ws + (r0 / SB) * (SB * SB)), bt.sb, bt.sk, bt.sws);
-    CIMRGP_LAUNCH_CHECK(fn);
+    const bool step_ok = knobs().rows_step != 0 && bt.count == 1 && m > 0;
+    const bool near_pending = grp.near_pending;
+    grp.near_pending = false;
+    if (step_ok && rw == CIMRGP_NB) {
+        int rcs = rows_step_launch<T>(b, ldb, m, lmat, ld, ws, r0, near_pending, st, fn);
+        if (rcs) return rcs;
+    } else {
+        if (near_pending) {                      // (cannot happen: the promise below is made for full panels only)
+            int rcn = gemm_nt_sub<T>(b + r0, ldb, b + r0 - CIMRGP_NB, ldb, lmat + r0 * ld + r0 - CIMRGP_NB, ld, m, rw, CIMRGP_NB, false, st, gb);
+            if (rcn) return rcn;
+        }
+        hipLaunchKernelGGL((k_trsm256<T>), dim3((unsigned)((m + TR - 1) / TR), (unsigned)bt.count), dim3(256), 0, st,
+                           b + r0, ldb, (int)m, (int)rw, (const T*)(lmat + r0 * ld + r0), ld,
+                           (const T*)(ws + (r0 / SB) * (SB * SB)), bt.sb, bt.sk, bt.sws);
+        CIMRGP_LAUNCH_CHECK(fn);
+    }
     if (n <= r1) { grp = PanelGroup(); return 0; }
     const int64_t rn = (n - r1 < CIMRGP_NB) ? (n - r1) : CIMRGP_NB;
     if (grp.g0 < 0) {
@@ -1735,6 +1952,12 @@ static int rows_panel_step(T* b, int64_t ldb, int64_t m, const T* lmat, int64_t 
     }
     const int64_t kk0 = (grp.g0 >= 0) ? grp.g0 : r0;
     grp = PanelGroup();
+    if (step_ok && kk0 == r0 && rw == CIMRGP_NB && rn == CIMRGP_NB) {
+        // the next panel's columns take this panel's update inside their own solve (k_rows_step)
+        grp.near_pending = true;
+        if (n <= r1 + rn) return 0;
+        return gemm_nt_sub<T>(b + r1 + rn, ldb, b + r0, ldb, lmat + (r1 + rn) * ld + r0, ld, m, n - (r1 + rn), (int)rw, false, st, gb);
+    }
     return gemm_nt_sub<T>(b + r1, ldb, b + kk0, ldb, lmat + r1 * ld + kk0, ld, m, n - r1, (int)(r1 - kk0), false, st, gb);
 }
 
@@ -2241,6 +2464,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     // start than 4608 trailing rows: 3072 / 5632 / 6656 / 8192 -> 89.2 / 94.3 / 91.6 / 89.5.)
     PanelGroup rows_grp;                               // carried rows: open group of panels whose far update is owed
     hipEvent_t ev_rows_far = nullptr;                  // carried rows: last far update queued on the second rows queue
+    hipEvent_t ev_rows_far_prev = nullptr;             // ... and the one before it
     // second rows queue: created when first wanted (cimrgp_set_rows_queues(1) before the first
     // factorisation with carried rows means it never exists: a process then holds four streams)
     if (rows && rows_queues() == 2 && la->rows_far == nullptr) {
@@ -2272,21 +2496,42 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
                 if (rcr) return rcr;
                 continue;
             }
-            // The rows' own chain -- 256-wide solve of panel r0 (65 workgroups, 31 us of a nearly idle
-            // machine), then the update of the NEXT panel's columns -- on `sq`; the update of everything
-            // beyond (the bulk of the flops) on a second queue, where it runs beside the next panel's
-            // solve instead of after it.  far(p) needs the solved columns of panel p only; near(p) and
-            // far(p - 1) both write the next panel's columns, so near(p) waits for far(p - 1).
-            hipLaunchKernelGGL((k_trsm256<T>), dim3((unsigned)((m + TR - 1) / TR)), dim3(256), 0, sq,
-                               b + r0, ldb, (int)m, (int)rw, (const T*)(k + r0 * ld + r0), ld,
-                               (const T*)(ws + (r0 / SB) * (SB * SB)));
-            CIMRGP_LAUNCH_CHECK("cimrgp_potrf_rows");
+            // The rows' own chain on `sq`: panel r0's solve with the previous panel's update of its columns fused in
+            // (k_rows_step; until round 4 a 64-tile update and k_trsm256, two latency-bound launches); the update of
+            // everything beyond the next panel (the bulk of the flops) on a second queue.  far(p) needs the solved
+            // columns of panel p only and writes the columns from panel p+2 on: the step of panel p+2 waits for it,
+            // the step of panel p+1 does not.
+            const bool step_ok = knobs().rows_step != 0;
+            const bool near_pending = rows_grp.near_pending;
+            rows_grp.near_pending = false;
+            if (step_ok && rw == CIMRGP_NB) {
+                if (near_pending && ev_rows_far_prev) CIMRGP_HIP_TRY(hipStreamWaitEvent(sq, ev_rows_far_prev, 0), "hipStreamWaitEvent");
+                int rcs = rows_step_launch<T>(b, ldb, m, k, ld, ws, r0, near_pending, sq, "cimrgp_potrf_rows");
+                if (rcs) return rcs;
+            } else {
+                if (near_pending) {              // (a promise is made for full panels only)
+                    if (ev_rows_far_prev) CIMRGP_HIP_TRY(hipStreamWaitEvent(sq, ev_rows_far_prev, 0), "hipStreamWaitEvent");
+                    int rcn = gemm_nt_sub<T>(b + r0, ldb, b + r0 - CIMRGP_NB, ldb, k + r0 * ld + r0 - CIMRGP_NB, ld, m, rw, CIMRGP_NB, false, sq);
+                    if (rcn) return rcn;
+                }
+                hipLaunchKernelGGL((k_trsm256<T>), dim3((unsigned)((m + TR - 1) / TR)), dim3(256), 0, sq,
+                                   b + r0, ldb, (int)m, (int)rw, (const T*)(k + r0 * ld + r0), ld,
+                                   (const T*)(ws + (r0 / SB) * (SB * SB)));
+                CIMRGP_LAUNCH_CHECK("cimrgp_potrf_rows");
+            }
             if (n <= r1) continue;
             hipEvent_t ev_w = la->ev[ne++];
             CIMRGP_HIP_TRY(hipEventRecord(ev_w, sq), "hipEventRecord");
-            if (ev_rows_far) CIMRGP_HIP_TRY(hipStreamWaitEvent(sq, ev_rows_far, 0), "hipStreamWaitEvent");
-            int rcr = gemm_nt_sub<T>(b + r1, ldb, b + r0, ldb, k + r1 * ld + r0, ld, m, rn, (int)rw, false, sq);
-            if (rcr) return rcr;
+            int rcr = 0;
+            // (not for the last panel of a forced catch-up: whoever continues expects these columns complete)
+            if (step_ok && rw == CIMRGP_NB && rn == CIMRGP_NB && !(force && r0 == k0)) {
+                rows_grp.near_pending = true;
+            } else {
+                if (ev_rows_far) CIMRGP_HIP_TRY(hipStreamWaitEvent(sq, ev_rows_far, 0), "hipStreamWaitEvent");
+                rcr = gemm_nt_sub<T>(b + r1, ldb, b + r0, ldb, k + r1 * ld + r0, ld, m, rn, (int)rw, false, sq);
+                if (rcr) return rcr;
+            }
+            ev_rows_far_prev = ev_rows_far;
             if (n > r1 + rn) {
                 hipStream_t sf = la->rows_far;
                 CIMRGP_HIP_TRY(hipStreamWaitEvent(sf, ev_w, 0), "hipStreamWaitEvent");
@@ -2311,6 +2556,14 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
                 ev_rows_far = la->ev[ne++];
                 CIMRGP_HIP_TRY(hipEventRecord(ev_rows_far, sf), "hipEventRecord");
             }
+        }
+        if (force && rows_grp.near_pending) {
+            // whoever continues (the fused sweep's riders) expects the next panel's columns complete
+            const int64_t fw = k1 - k0, fn_ = (n - k1 < CIMRGP_NB) ? (n - k1) : CIMRGP_NB;
+            if (ev_rows_far) CIMRGP_HIP_TRY(hipStreamWaitEvent(sq, ev_rows_far, 0), "hipStreamWaitEvent");
+            int rcn = gemm_nt_sub<T>(b + k1, ldb, b + k0, ldb, k + k1 * ld + k0, ld, m, fn_, (int)fw, false, sq);
+            if (rcn) return rcn;
+            rows_grp.near_pending = false;
         }
         rows_next = k1;
         return 0;
