@@ -284,6 +284,9 @@ def main():
                     help="2: the headline N = 8192 block per GPU (default); 3 / 4: BASELINE configs[2] / [3], the "
                          "multiresolution hierarchy with its blocks sharded over the ranks (--n scales it down)")
     ap.add_argument("--check", action="store_true", help="--config 3/4: compare with the CPU oracle (done anyway for n <= 16384)")
+    ap.add_argument("--pipeline", type=int, default=-1, choices=[-1, 0, 1],
+                    help="1: consecutive (independent) blocks pipelined over three streams and three buffer sets "
+                         "(cimrgp_block_posterior_staged); 0: one stream, one set; default: 1 unless ranks share one GPU")
     ap.add_argument("--nccl-world1", action="store_true",
                     help="one rank, backend nccl initialised, the step's reduce goes through RCCL unconditionally")
     ap.add_argument("--rows-queues", type=int, default=0, choices=[0, 1, 2],
@@ -340,37 +343,87 @@ def main():
     xsd = dev.to_device(workloads.block_test_points(ns), tdt, device)
 
     # Buffers allocated once.  The timed step is ONE call of the boundary's fused entry point,
-    # cimrgp_block_posterior (include/cimrgp.h: Gram, cross-Gram and target rows, factorisation with the rows
+    # cimrgp_block_posterior[_staged] (include/cimrgp.h: Gram, cross-Gram and target rows, factorisation with the rows
     # carried, backward solve, mean and variance), on these buffers: no torch kernel and no allocation inside it.
     # Its outputs land directly in this rank's slices of the fused [mean (ns_total x q) | var (ns_total)] buffer of
     # the step's one collective.
-    kbuf = dev.alloc_matrix(n, n, tdt, device)
-    wbuf = dev.alloc_matrix(ns + q, n, tdt, device)      # carried rows: [K(X*, X); r^T]
-    ws = dev.potrf_workspace(n, tdt, device)
-    info = torch.zeros(1, dtype=torch.int32, device=device)
+    # Consecutive steps are INDEPENDENT blocks (the partitions of a layer), so they are pipelined: two buffer sets in
+    # rotation, and the call's last stage -- the latency-bound backward solve and prediction (0.33 ms of 62 small
+    # launches) -- on the look-ahead context's queue that is idle between two factorisations (cimrgp_solve_queue), beside
+    # the Gram matrices and first panels of the next step.  (A stream of the bench's own for that stage is a fifth
+    # queue for a runtime that serves four: 8.1 -> 10.2 ms per step; tools/lab/pipeline_probe.py.)
+    # Every step's work is complete inside the timed region (device-wide synchronisation on both sides).
+    pipeline = (args.pipeline == 1) or (args.pipeline == -1 and not (rehearsal and world > 1))
+    nsets = 2 if pipeline else 1
     nst = ns * world
-    fused = torch.zeros(nst * (q + 1), dtype=tdt, device=device)
-    mean = fused[:nst * q].view(nst, q)[rank * ns:(rank + 1) * ns]          # (ns x q), contiguous
-    var = fused[nst * q:][rank * ns:(rank + 1) * ns]                        # (ns,)
-    alpha = torch.empty((n, q), dtype=tdt, device=device)
-    zbuf = torch.empty((n, q), dtype=tdt, device=device)
-    scratch = torch.empty(2 * q * n, dtype=tdt, device=device)
-    others = [fused[:nst * q].view(nst, q)[:rank * ns], fused[:nst * q].view(nst, q)[(rank + 1) * ns:],
-              fused[nst * q:][:rank * ns], fused[nst * q:][(rank + 1) * ns:]] if world > 1 else []
+
+    def make_set():
+        b = dict(kbuf=dev.alloc_matrix(n, n, tdt, device),
+                 wbuf=dev.alloc_matrix(ns + q, n, tdt, device),      # carried rows: [K(X*, X); r^T]
+                 ws=dev.potrf_workspace(n, tdt, device),
+                 info=torch.zeros(1, dtype=torch.int32, device=device),
+                 fused=torch.zeros(nst * (q + 1), dtype=tdt, device=device),
+                 alpha=torch.empty((n, q), dtype=tdt, device=device),
+                 zbuf=torch.empty((n, q), dtype=tdt, device=device),
+                 scratch=torch.empty(2 * q * n, dtype=tdt, device=device))
+        f = b["fused"]
+        b["mean"] = f[:nst * q].view(nst, q)[rank * ns:(rank + 1) * ns]          # (ns x q), contiguous
+        b["var"] = f[nst * q:][rank * ns:(rank + 1) * ns]                        # (ns,)
+        b["others"] = [f[:nst * q].view(nst, q)[:rank * ns], f[:nst * q].view(nst, q)[(rank + 1) * ns:],
+                       f[nst * q:][:rank * ns], f[nst * q:][(rank + 1) * ns:]] if world > 1 else []
+        return b
+
+    sets = [make_set() for _ in range(nsets)]
+    kbuf, wbuf, ws, info, mean, var = (sets[0][k] for k in ("kbuf", "wbuf", "ws", "info", "mean", "var"))
+    streams = None                                                                    # front, factor, solve
+    if pipeline:
+        cur = torch.cuda.current_stream()
+        streams = (cur, cur, dev.solve_queue(cur))
+    pending = [None] * nsets                 # the set's collective in flight
+    done = [None] * nsets                    # (pipeline) the set's last reader on the solve stream
+    step_no = [0]
+    last_set = [0]
 
     def step(wait_inside=False):
-        # the previous step's collective owns `fused` until it is done: the STREAM waits for it here (the host does
-        # not block), a whole step after it was started
-        if pending[0] is not None:
-            pending[0].wait()
-            pending[0] = None
-        for t in others:                                                        # the other ranks' slices (world > 1 only)
-            t.zero_()
-        dev.block_posterior(xd, yd, xsd, ell, sf2, noise, kbuf, wbuf, ws, info, alpha, zbuf, mean, var, scratch=scratch)
-        pending[0] = dist.allreduce_sum_begin(fused, force=args.nccl_world1)        # the one collective
-        if wait_inside and pending[0] is not None:
-            pending[0].wait()
-            pending[0] = None
+        si = step_no[0] % nsets
+        step_no[0] += 1
+        last_set[0] = si
+        b = sets[si]
+        if not pipeline:
+            # the previous step's collective owns `fused` until it is done: the STREAM waits for it here (the host does
+            # not block), a whole step after it was started
+            if pending[si] is not None:
+                pending[si].wait()
+                pending[si] = None
+            for t in b["others"]:                                                   # the other ranks' slices (world > 1 only)
+                t.zero_()
+            dev.block_posterior(xd, yd, xsd, ell, sf2, noise, b["kbuf"], b["wbuf"], b["ws"], b["info"], b["alpha"], b["zbuf"],
+                                b["mean"], b["var"], scratch=b["scratch"])
+            pending[si] = dist.allreduce_sum_begin(b["fused"], force=args.nccl_world1)    # the one collective
+            if wait_inside and pending[si] is not None:
+                pending[si].wait()
+                pending[si] = None
+            return
+        s_front, s_factor, s_solve = streams
+        # the set comes back after nsets steps: its collective (started nsets steps ago) and its solve are waited for by
+        # the front stream, not by the host
+        with torch.cuda.stream(s_front):
+            if pending[si] is not None:
+                pending[si].wait()
+                pending[si] = None
+            if done[si] is not None:
+                s_front.wait_event(done[si])
+            for t in b["others"]:
+                t.zero_()
+        dev.block_posterior(xd, yd, xsd, ell, sf2, noise, b["kbuf"], b["wbuf"], b["ws"], b["info"], b["alpha"], b["zbuf"],
+                            b["mean"], b["var"], scratch=b["scratch"], streams=streams)
+        with torch.cuda.stream(s_solve):
+            pending[si] = dist.allreduce_sum_begin(b["fused"], force=args.nccl_world1)    # the one collective
+            if wait_inside and pending[si] is not None:
+                pending[si].wait()
+                pending[si] = None
+            done[si] = torch.cuda.Event()
+            done[si].record(s_solve)
 
     # the same work as five separate calls (the boundary's fine-grained entry points), with an event between the
     # stages: run AFTER the timed region, for `stage_ms` only (tests/ hold the two forms to bit-equality)
@@ -390,12 +443,11 @@ def main():
         dev.predict_from_w(wbuf, ns, n, z, sf2, 0.0, None, mean, var, accumulate=False)   # D4 + D5 tail
         ev[4].record()
 
-    pending = [None]
-
     def drain():
-        if pending[0] is not None:
-            pending[0].wait()
-            pending[0] = None
+        for si in range(nsets):
+            if pending[si] is not None:
+                pending[si].wait()
+                pending[si] = None
 
     def barrier():
         if world > 1:
@@ -406,7 +458,7 @@ def main():
         step()
     drain()
     barrier()
-    assert int(info.item()) == 0, "Cholesky failed in warm-up"
+    assert all(int(b["info"].item()) == 0 for b in sets), "Cholesky failed in warm-up"
 
     # The roofline's live timing: HIP events around the trailing-update launches, on their own stream, in every
     # EVENT_EVERY-th timed step (two event records per launch on the update queue cost ~1 % of a step when every
@@ -425,8 +477,8 @@ def main():
     tr_ms, tr_fl, tr_by, tr_cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
     _lib.check(lib.cimrgp_profile_collect_bytes(ctypes.byref(tr_ms), ctypes.byref(tr_fl), ctypes.byref(tr_by), ctypes.byref(tr_cnt)),
                "cimrgp_profile_collect_bytes")
-    last_mean = mean.double().cpu().numpy()                    # the last timed step's outputs (this rank)
-    last_var = var.double().cpu().numpy()
+    last_mean = sets[last_set[0]]["mean"].double().cpu().numpy()     # the last timed step's outputs (this rank)
+    last_var = sets[last_set[0]]["var"].double().cpu().numpy()
     # the collective of the timed steps is started at the end of a step and waited for (by the stream) at the start
     # of the next: its latency is hidden.  What it costs when it is NOT hidden: steps that wait for it inside.
     drained_ms = None
@@ -439,10 +491,12 @@ def main():
         drained_ms = (time.perf_counter() - t1) / 5 * 1e3
     # the reduced buffer holds this rank's slice unchanged (the other ranks contribute zeros there): exact
     step()
-    mine = torch.cat([mean.reshape(-1), var]).clone()
+    lb = sets[last_set[0]]
+    with torch.cuda.stream(streams[2] if pipeline else torch.cuda.current_stream()):
+        mine = torch.cat([lb["mean"].reshape(-1), lb["var"]]).clone()
     drain()
     torch.cuda.synchronize()
-    reduce_diff = float((torch.cat([mean.reshape(-1), var]) - mine).abs().max().item())
+    reduce_diff = float((torch.cat([lb["mean"].reshape(-1), lb["var"]]) - mine).abs().max().item())
     # stage times: the five-call form, outside the timed region (median of 3 after a warm-up)
     stage_runs = []
     for rep in range(4):
@@ -500,7 +554,12 @@ def main():
             "reduce_selfcheck_max_abs_diff": reduce_diff,
             "cholesky_gflops": chol_gflops,
             "cholesky_frac_of_peak": chol_gflops / 1e3 / peak,
-            "step_is": "ONE cimrgp_block_posterior call per step on preallocated buffers (+ the collective's enqueue)",
+            "step_is": ("ONE cimrgp_block_posterior_staged call per step on preallocated buffers (+ the collective's enqueue): consecutive steps "
+                        "are independent blocks over two rotating buffer sets; the backward solve and prediction of step i run on the "
+                        "look-ahead context's idle queue (cimrgp_solve_queue) beside the Gram matrices and first panels of step i+1; "
+                        "every step completes inside the timed region")
+                       if pipeline else "ONE cimrgp_block_posterior call per step on preallocated buffers (+ the collective's enqueue)",
+            "pipelined_steps": bool(pipeline),
             "reduce_overlapped": bool(world > 1 or args.nccl_world1),
             "drained_step_ms": drained_ms,
             "stage_ms": {"measured": "the same work as five separate calls, after the timed region (median of 3)",

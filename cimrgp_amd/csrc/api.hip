@@ -1,5 +1,6 @@
 // extern "C" entry points of libcimrgp.so (declared in include/cimrgp.h).
 #include "common.hpp"
+#include <mutex>
 
 #include <string.h>
 #include <stdlib.h>
@@ -48,6 +49,8 @@ const Knobs& knobs()
         v.batch_halves_min = (int)num("CIMRGP_BATCH_HALVES", v.batch_halves_min);
         v.rows_cus = (int)num("CIMRGP_ROWS_CUS", v.rows_cus);
         v.rows_step = (int)num("CIMRGP_ROWS_STEP", v.rows_step);
+        v.rider_lean = (int)num("CIMRGP_RIDER_LEAN", v.rider_lean);
+        v.rider_round_us = (int)num("CIMRGP_RIDER_ROUND", v.rider_round_us);
         v.trsm_group = (int)num("CIMRGP_TRSM_GROUP", v.trsm_group);
         v.rows_beside_tail_below = num("CIMRGP_ROWS_BESIDE", v.rows_beside_tail_below);
         v.tail_far_cus = (int)num("CIMRGP_TAIL_FAR_CUS", v.tail_far_cus);
@@ -122,19 +125,67 @@ namespace {
 template <typename T>
 int block_posterior_typed(const void* x, int64_t n, int d, const void* y, int q, const void* xs, int64_t ns, double ell, double sf2,
                           double noise, void* k, int64_t ldk, void* ws, int32_t* info, void* w, int64_t ldw, void* alpha, void* z,
-                          void* scratch, void* mean, void* var, int add_noise, int accumulate, hipStream_t st)
+                          void* scratch, void* mean, void* var, int add_noise, int accumulate,
+                          hipStream_t s_front, hipStream_t st, hipStream_t s_solve)
 {
     using namespace cimrgp;
+    const char* fn = "cimrgp_block_posterior";
     T* wt = (T*)w;
-    int rc = rbf_gram_run<T>((const T*)x, n, (const T*)x, n, d, ell, sf2, noise, (T*)k, ldk, true, true, st);
-    if (!rc && ns > 0) rc = rbf_gram_run<T>((const T*)xs, ns, (const T*)x, n, d, ell, sf2, 0.0, wt, ldw, false, false, st);
-    if (!rc) rc = rhs_rows_run<T>((const T*)y, n, q, wt + ns * ldw, ldw, st);
+    // `to` continues where `from` stands now (an event that lives until both have passed it)
+    auto hand_over = [&](hipStream_t from, hipStream_t to) -> int {
+        if (from == to) return 0;
+        // a ring of events created once (a wait captures the record that precedes it: an event may be recorded again
+        // while an earlier wait on it is still queued)
+        static std::mutex ring_mutex;
+        static hipEvent_t ring[64] = {};
+        static unsigned ring_next = 0;
+        hipEvent_t e = nullptr;
+        {
+            std::lock_guard<std::mutex> guard(ring_mutex);
+            hipEvent_t& slot = ring[ring_next++ % 64];
+            if (slot == nullptr) {
+                hipError_t e0 = hipEventCreateWithFlags(&slot, hipEventDisableTiming);
+                if (e0 != hipSuccess) { slot = nullptr; return check_hip(e0, fn, "hipEventCreate"); }
+            }
+            e = slot;
+        }
+        hipError_t e1 = hipEventRecord(e, from);
+        hipError_t e2 = (e1 == hipSuccess) ? hipStreamWaitEvent(to, e, 0) : e1;
+        return check_hip(e2, fn, "hipEventRecord / hipStreamWaitEvent");
+    };
+    // front end: the Gram matrix, the cross-Gram matrix and the targets as carried rows
+    int rc = rbf_gram_run<T>((const T*)x, n, (const T*)x, n, d, ell, sf2, noise, (T*)k, ldk, true, true, s_front);
+    if (!rc && ns > 0) rc = rbf_gram_run<T>((const T*)xs, ns, (const T*)x, n, d, ell, sf2, 0.0, wt, ldw, false, false, s_front);
+    if (!rc) rc = rhs_rows_run<T>((const T*)y, n, q, wt + ns * ldw, ldw, s_front);
+    if (!rc) rc = hand_over(s_front, st);
     if (!rc) rc = potrf_run<T>((T*)k, n, ldk, (T*)ws, info, wt, ns + q, ldw, st);
+    if (!rc) rc = hand_over(st, s_solve);
+    // Two buffer sets in rotation need no ordering by the caller: behind its factorisation `st` waits for the solve
+    // stage of the PREVIOUS call on the same pair of streams (finished long ago: it ran beside this factorisation), so
+    // whatever the caller enqueues on `st` next -- the front end of the call after this one, on the set that solve
+    // stage read -- comes after it.
+    static std::mutex last_mutex;
+    static hipStream_t last_st = nullptr, last_solve = nullptr;
+    static hipEvent_t last_event = nullptr;          // created once, recorded behind every separate solve stage
+    if (!rc && s_solve != st) {
+        std::lock_guard<std::mutex> guard(last_mutex);
+        if (last_event != nullptr && last_st == st && last_solve == s_solve)
+            rc = check_hip(hipStreamWaitEvent(st, last_event, 0), fn, "hipStreamWaitEvent");
+    }
     // z = L^-1 y (the last q carried rows), alpha = L^-T z, mean = W z, var = sf2 - sum W^2 (+ noise)
-    if (!rc) rc = rows_to_z_run<T>(wt + ns * ldw, ldw, n, q, (T*)z, (T*)alpha, st);
-    if (!rc) rc = potrs_run<T>((const T*)k, n, ldk, (const T*)ws, (T*)alpha, q, nullptr, (T*)scratch, true, st);
+    if (!rc) rc = rows_to_z_run<T>(wt + ns * ldw, ldw, n, q, (T*)z, (T*)alpha, s_solve);
+    if (!rc) rc = potrs_run<T>((const T*)k, n, ldk, (const T*)ws, (T*)alpha, q, nullptr, (T*)scratch, true, s_solve);
     if (!rc && ns > 0) rc = predict_from_w_run<T>((const T*)w, ns, n, ldw, (const T*)z, q, sf2, add_noise ? noise : 0.0, nullptr, nullptr,
-                                                   (T*)mean, (T*)var, accumulate, st, 1, nullptr, 0);
+                                                   (T*)mean, (T*)var, accumulate, s_solve, 1, nullptr, 0);
+    if (!rc && s_solve != st) {
+        std::lock_guard<std::mutex> guard(last_mutex);
+        if (last_event == nullptr && hipEventCreateWithFlags(&last_event, hipEventDisableTiming) != hipSuccess) last_event = nullptr;
+        if (last_event != nullptr) {
+            rc = check_hip(hipEventRecord(last_event, s_solve), fn, "hipEventRecord");
+            last_st = st;
+            last_solve = s_solve;
+        }
+    }
     return rc;
 }
 }  // namespace
@@ -222,6 +273,25 @@ int cimrgp_block_posterior(int dtype, const void* x_dev, int64_t n, int d, const
                            size_t workspace_bytes, int32_t* info_dev, void* w_dev, int64_t ldw, void* alpha_dev, void* z_dev,
                            void* scratch_dev, void* mean_dev, void* var_dev, int add_noise, int accumulate, void* stream)
 {
+    return cimrgp_block_posterior_staged(dtype, x_dev, n, d, y_dev, q, xs_dev, ns, ell, sf2, noise, k_dev, ldk, workspace_dev, workspace_bytes,
+                                         info_dev, w_dev, ldw, alpha_dev, z_dev, scratch_dev, mean_dev, var_dev, add_noise, accumulate,
+                                         stream, stream, stream);
+}
+
+int cimrgp_solve_queue(void* stream, void** queue_out)
+{
+    const char* fn = "cimrgp_solve_queue";
+    CIMRGP_REQUIRE(queue_out != nullptr, fn, "null pointer");
+    *queue_out = (void*)cimrgp::solve_queue_for(S(stream));
+    return 0;
+}
+
+int cimrgp_block_posterior_staged(int dtype, const void* x_dev, int64_t n, int d, const void* y_dev, int q, const void* xs_dev, int64_t ns,
+                                  double ell, double sf2, double noise, void* k_dev, int64_t ldk, void* workspace_dev,
+                                  size_t workspace_bytes, int32_t* info_dev, void* w_dev, int64_t ldw, void* alpha_dev, void* z_dev,
+                                  void* scratch_dev, void* mean_dev, void* var_dev, int add_noise, int accumulate,
+                                  void* stream_front, void* stream, void* stream_solve)
+{
     const char* fn = "cimrgp_block_posterior";
     CIMRGP_REQUIRE(x_dev && y_dev && k_dev && workspace_dev && info_dev && w_dev && alpha_dev && z_dev && scratch_dev, fn, "null pointer");
     CIMRGP_REQUIRE(ns == 0 || (xs_dev && mean_dev && var_dev), fn, "null pointer (test points)");
@@ -233,9 +303,11 @@ int cimrgp_block_posterior(int dtype, const void* x_dev, int64_t n, int d, const
     CIMRGP_REQUIRE(workspace_bytes >= cimrgp_potrf_workspace_bytes(dtype, n), fn, "workspace too small");
     DISPATCH(dtype, fn,
              block_posterior_typed<float>(x_dev, n, d, y_dev, q, xs_dev, ns, ell, sf2, noise, k_dev, ldk, workspace_dev, info_dev, w_dev, ldw,
-                                          alpha_dev, z_dev, scratch_dev, mean_dev, var_dev, add_noise, accumulate, S(stream)),
+                                          alpha_dev, z_dev, scratch_dev, mean_dev, var_dev, add_noise, accumulate, S(stream_front), S(stream),
+                                          S(stream_solve)),
              block_posterior_typed<double>(x_dev, n, d, y_dev, q, xs_dev, ns, ell, sf2, noise, k_dev, ldk, workspace_dev, info_dev, w_dev, ldw,
-                                           alpha_dev, z_dev, scratch_dev, mean_dev, var_dev, add_noise, accumulate, S(stream)));
+                                           alpha_dev, z_dev, scratch_dev, mean_dev, var_dev, add_noise, accumulate, S(stream_front), S(stream),
+                                           S(stream_solve)));
 }
 
 int cimrgp_potrf_rows_batched(int dtype, void* k_dev, int64_t n, int64_t ldk, int64_t k_stride, void* workspace_dev,

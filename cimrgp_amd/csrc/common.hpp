@@ -120,6 +120,8 @@ struct Knobs {
     int64_t fused_max_chain_wgs = 768;     // CIMRGP_FUSED_MAX: one-queue sweeps ride their updates in the chain's launches while batch x n / 32 is at most this
     int batch_halves_min = 8;              // CIMRGP_BATCH_HALVES: a batched factorisation of at least this many blocks (that does not ride) runs as two halves on two queues
     int rows_step = 1;                     // CIMRGP_ROWS_STEP: carried rows' chain as one launch per panel (k_rows_step: previous panel's update + 256-wide solve; 0: update and k_trsm256 as two launches)
+    int rider_lean = 1;                    // CIMRGP_RIDER_LEAN: one-queue sweeps give rounds of K = 256 riders to the links first (0: every launch starts with one round)
+    int rider_round_us = 25;               // CIMRGP_RIDER_ROUND: modelled duration of one round of K = 256 rider tiles (us)
     int rows_cus = 224;                    // CIMRGP_ROWS_CUS: compute units of the carried rows' far updates (persistent kernel; 0: tile-per-workgroup kernel)
     int trsm_group = 1;                    // CIMRGP_TRSM_GROUP: batched launches solve 4 row tiles per workgroup (0: one)
     int64_t rows_beside_tail_below = 2560; // CIMRGP_ROWS_BESIDE: with carried rows, the factorisation's tail (trailing matrix at most this) is the one-queue fused sweep while the rows keep their own queues (0: look-ahead to the end)
@@ -130,6 +132,8 @@ struct Knobs {
 const Knobs& knobs();
 // Queues for the carried rows of cimrgp_potrf_rows (1 or 2): cimrgp_set_rows_queues in include/cimrgp.h.
 int rows_queues();
+// (potrf.hip) the look-ahead context's queue that is idle between two factorisations on st: cimrgp_solve_queue
+hipStream_t solve_queue_for(hipStream_t st);
 
 // --------------------------------------------------------- host launchers ----
 // potrf.hip

@@ -2052,7 +2052,11 @@ static int fused_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, T* 
         if (e != hipSuccess) return check_hip(e, fn, "hipEventRecord");
     }
     // the chain parts of the five launches last about this long alone (us)
-    static const double chain_us[5] = {17.0, 22.0, 27.0, 31.0, 12.0};
+    // (round 4, knobs().rider_lean: as measured in the tail of an N = 8192 factorisation without riders' help)
+    static const double chain_us_r3[5] = {17.0, 22.0, 27.0, 31.0, 12.0};
+    static const double chain_us_r4[5] = {15.0, 21.0, 24.0, 28.0, 13.0};
+    const bool lean = knobs().rider_lean != 0;
+    const double* chain_us = lean ? chain_us_r4 : chain_us_r3;
     int64_t q0 = (prev_w > 0) ? k_begin - prev_w : -1;      // previous panel (-1: none)
     int64_t qw = prev_w;
     bool ph3_pending = false;                                // prev's last sub-block still owed to this panel's columns
@@ -2123,7 +2127,7 @@ static int fused_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, T* 
                 // takes two rounds' time: the first version of this schedule, split by the chain parts'
                 // durations, took 221 us per panel at 4352 trailing rows where 7 packed rounds take ~150).
                 const int slots = 2 * (far_on_bulk ? 256 - fb->cus : 256);
-                const double t_round = 20.0;
+                const double t_round = lean ? (double)knobs().rider_round_us : 20.0;
                 const int64_t rows_below = n - k1;
                 int nchain_i[5], fixed_i[5];
                 for (int i = 0; i < 5; ++i) {
@@ -2136,7 +2140,12 @@ static int fused_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, T* 
                 // about a third of a K = 256 tile each)
                 fixed_i[0] = (int)(ph3_tiles / 3 + rows_near_tiles);
                 if (w == CIMRGP_NB) for (int i = 2; i < 5; ++i) fixed_i[i] = (int)(tiles64(n - k1) * tiles64(wn)) / 3;
+                // Round 4 (lean): a launch starts with NO round of K = 256 riders; rounds go first to the launches whose
+                // chain part outlasts a round anyway (the links), and the first diagonal kernel and the last solve --
+                // 15 and 13 us alone, 25-29 and 16 with a round of riders -- take riders only when the links are full.
+                // (Until round 4 every launch started with one round, and NEAR and FAR filled launch 0 first.)
                 int rounds[5] = {1, 1, 1, 1, 1};
+                if (lean) for (int i = 0; i < 5; ++i) rounds[i] = 0;
                 auto capacity = [&](int i) { const int64_t c = (int64_t)rounds[i] * (slots - nchain_i[i]) - fixed_i[i]; return c > 0 ? c : 0; };
                 const int64_t need = near_tiles + far_tiles + rows_far_tiles;
                 for (;;) {
@@ -2159,6 +2168,7 @@ static int fused_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, T* 
                 // NEAR(prev): launches 0 and 1 only (from launch 2 on this panel's sub-blocks update the same columns)
                 RiderJob<T> nr = rect_job(kmat + k1 * ld + k1, ld, pa + k1 * ld, ld, pa + k1 * ld, ld, n - k1, wn, qw);
                 int64_t near0 = capacity(0) < near_tiles ? capacity(0) : near_tiles;
+                if (lean) near0 = 0;                                                         // the first link before the diagonal kernel
                 if (near_tiles - near0 > capacity(1)) near0 = near_tiles - capacity(1);     // (capacities cover it: near_ok)
                 RiderJob<T> n0 = nr; n0.first = 0; n0.count = (int)near0; add(0, n0);
                 RiderJob<T> n1 = nr; n1.first = (int)near0; n1.count = (int)(near_tiles - near0); add(1, n1);
@@ -2174,14 +2184,17 @@ static int fused_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, T* 
                         rf.rows_job = 1;
                     }
                     int64_t done_f = 0, done_r = 0;
-                    for (int i = 0; i < 5; ++i) {
+                    static const int order_r3[5] = {0, 1, 2, 3, 4}, order_r4[5] = {1, 2, 3, 0, 4};
+                    const int* order = lean ? order_r4 : order_r3;
+                    for (int oi = 0; oi < 5; ++oi) {
+                        const int i = order[oi];
                         int64_t room = capacity(i) - (i == 0 ? near0 : i == 1 ? (near_tiles - near0) : 0);
                         if (room < 0) room = 0;
                         int64_t take_f = far_tiles - done_f;
-                        if (i < 4 && take_f > room) take_f = room;
+                        if (oi < 4 && take_f > room) take_f = room;
                         room -= take_f;
                         int64_t take_r = rows_far_tiles - done_r;
-                        if (i < 4 && take_r > room) take_r = (room > 0 ? room : 0);
+                        if (oi < 4 && take_r > room) take_r = (room > 0 ? room : 0);
                         if (take_f > 0) { RiderJob<T> part = fr; part.first = (int)done_f; part.count = (int)take_f; add(i, part); }
                         if (take_r > 0) { RiderJob<T> part = rf; part.first = (int)done_r; part.count = (int)take_r; add(i, part); }
                         done_f += take_f;
@@ -2359,6 +2372,18 @@ int factor_panel(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, int64_t k
     return panel_chain<T>(kmat, n, ld, ws, info, k0, w, (T*)nullptr, 0, 0, PotrfBatch(), st, "cimrgp_potrf", alone, first_done);
 }
 }  // namespace
+
+// The queue of `st`'s look-ahead context that is idle between two factorisations on `st` (the carried rows' own
+// queue: the rows of a factorisation start ~2 ms after its first panel at N = 8192): a caller that pipelines independent
+// blocks runs the latency-bound solve / prediction of block i there, beside the first panels of block i+1
+// (cimrgp_solve_queue).  A fifth stream of the caller's own for that purpose costs more than it hides (measured: 8.1 ->
+// 10.2 ms per step; the runtime serves four hardware queues).  `st` itself when it owns no context.
+hipStream_t solve_queue_for(hipStream_t st)
+{
+    LookAhead* la = acquire_ctx(st);
+    return (la != nullptr && la->owner == st && la->rows != nullptr) ? la->rows : st;
+}
+
 
 int potrf_shutdown()
 {

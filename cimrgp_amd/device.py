@@ -4,6 +4,8 @@ torch is used for device memory, streams and (elsewhere) torch.distributed --
 plumbing only; every arithmetic operation of the path below is a hand-written
 HIP kernel reached through ``libcimrgp.so``.
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -123,12 +125,15 @@ def potrf_rows(kbuf, n, bbuf, m, ws=None, info=None):
 
 
 def block_posterior(x, y, xs, ell, sf2, noise, kbuf, wbuf, ws, info, alpha, z, mean, var, add_noise=False, accumulate=False,
-                    scratch=None):
+                    scratch=None, streams=None):
     """One block's whole posterior in ONE call (cimrgp_block_posterior, include/cimrgp.h): Gram matrix, factorisation with
     the cross-Gram rows and the targets carried, backward solve, predictive mean and variance -- the same kernels as the
     separate calls.  kbuf (n x ld), wbuf ((ns + q) x ld), ws / info as for potrf; alpha, z (n x q),
     mean (ns x q), var (ns) are filled.  ``scratch``: 2 q n elements (allocated here when not given: a caller that
-    must not allocate between two events -- bench.py's timed step -- passes its own)."""
+    must not allocate between two events -- bench.py's timed step -- passes its own).
+    ``streams`` = (front, factor, solve) torch streams: the three stages on three streams
+    (cimrgp_block_posterior_staged), for callers that pipeline independent blocks over rotating buffer sets and order
+    the reuse of a set themselves; results are then ordered on ``solve``."""
     lib = _lib.load()
     n, d = x.shape
     q = y.shape[1]
@@ -137,11 +142,32 @@ def block_posterior(x, y, xs, ell, sf2, noise, kbuf, wbuf, ws, info, alpha, z, m
         scratch = torch.empty(2 * q * max(int(n), 1), dtype=x.dtype, device=x.device)
     elif scratch.numel() < 2 * q * max(int(n), 1) or scratch.dtype != x.dtype:
         raise ValueError("scratch must hold 2 q n elements of the block's dtype")
+    if streams is not None:
+        sf, sp, sq = (s.cuda_stream for s in streams)
+        _lib.check(lib.cimrgp_block_posterior_staged(_DT[x.dtype], _p(x), int(n), int(d), _p(y), int(q), _p(xs), int(ns), float(ell),
+                                                     float(sf2), float(noise), _p(kbuf), kbuf.stride(0), _p(ws), ws.numel(), _p(info),
+                                                     _p(wbuf), wbuf.stride(0), _p(alpha), _p(z), _p(scratch), _p(mean), _p(var),
+                                                     int(bool(add_noise)), int(bool(accumulate)), sf, sp, sq),
+                   "cimrgp_block_posterior_staged")
+        return mean, var
     _lib.check(lib.cimrgp_block_posterior(_DT[x.dtype], _p(x), int(n), int(d), _p(y), int(q), _p(xs), int(ns), float(ell), float(sf2),
                                           float(noise), _p(kbuf), kbuf.stride(0), _p(ws), ws.numel(), _p(info), _p(wbuf),
                                           wbuf.stride(0), _p(alpha), _p(z), _p(scratch), _p(mean), _p(var), int(bool(add_noise)),
                                           int(bool(accumulate)), _stream()), "cimrgp_block_posterior")
     return mean, var
+
+
+def solve_queue(stream=None):
+    """The stream to pass as ``streams[2]`` of :func:`block_posterior` (cimrgp_solve_queue, include/cimrgp.h): the
+    look-ahead context's queue that is idle between two factorisations on ``stream`` (default: the current stream),
+    wrapped as a torch stream; ``stream`` itself when it owns no context."""
+    lib = _lib.load()
+    cur = torch.cuda.current_stream() if stream is None else stream
+    out = ctypes.c_void_p()
+    _lib.check(lib.cimrgp_solve_queue(cur.cuda_stream, ctypes.byref(out)), "cimrgp_solve_queue")
+    if (out.value or 0) == (cur.cuda_stream or 0):
+        return cur
+    return torch.cuda.ExternalStream(out.value, device=cur.device)
 
 
 def potrf_rows_batched(karena, n, ld, ws_arena, info, barena=None, m=0, ldb=0):

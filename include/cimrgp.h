@@ -110,6 +110,29 @@ int cimrgp_block_posterior(int dtype, const void* x_dev, int64_t n, int d, const
                            int32_t* info_dev, void* w_dev, int64_t ldw, void* alpha_dev, void* z_dev,
                            void* scratch_dev, void* mean_dev, void* var_dev, int add_noise,
                            int accumulate, void* stream);
+/* The same call with its three stages on three streams, for a caller that pipelines INDEPENDENT blocks (the
+ * partitions of one layer: the reference's loop over regions, src/Posteriors.py:35-59, has no dependency between
+ * its iterations): the front end (Gram matrix, cross-Gram matrix, targets as carried rows) on stream_front, the
+ * factorisation with the carried rows on stream (the look-ahead context belongs to this one), backward solve and
+ * prediction on stream_solve; each stage starts when the one before it is done (events).  With three buffer sets in
+ * rotation the front end of block i+1 and the latency-bound solve of block i-1 run beside the factorisation of block
+ * i.  Reuse of a buffer set: behind its factorisation, `stream` waits for the solve stage of the previous call on the
+ * same (stream, stream_solve) pair, so with stream_front == stream and TWO sets in rotation the caller orders nothing;
+ * in every other arrangement the caller orders the reuse itself (stream_front must wait for the stream_solve work
+ * that last read the set).  Results: k_dev is final on stream, alpha / z / mean / var on stream_solve.  Bit-identical to
+ * cimrgp_block_posterior; equal streams give exactly that call. */
+int cimrgp_block_posterior_staged(int dtype, const void* x_dev, int64_t n, int d, const void* y_dev, int q,
+                                  const void* xs_dev, int64_t ns, double ell, double sf2, double noise,
+                                  void* k_dev, int64_t ldk, void* workspace_dev, size_t workspace_bytes,
+                                  int32_t* info_dev, void* w_dev, int64_t ldw, void* alpha_dev, void* z_dev,
+                                  void* scratch_dev, void* mean_dev, void* var_dev, int add_noise,
+                                  int accumulate, void* stream_front, void* stream, void* stream_solve);
+/* A queue for stream_solve that costs no hardware queue of its own: the queue of `stream`'s look-ahead context that
+ * is idle between two factorisations on `stream` (a process is served by four hardware queues and a factorisation with
+ * carried rows uses four; a fifth stream for the solve stage made the step 25 % longer, this one 4 % shorter).  The
+ * caller orders its own reads of the solve stage's results (an event on *queue_out).  *queue_out = stream when no
+ * context can be had for `stream` (then nothing overlaps).  The queue lives until cimrgp_shutdown. */
+int cimrgp_solve_queue(void* stream, void** queue_out);
 /* `batch` equal-sized factorisations -- the blocks of one layer (independent over regions,
  * Posteriors.py:35-59) -- in the SAME kernel launches: matrix i starts k_stride elements after
  * matrix i-1 (likewise workspace_stride_bytes, b_stride), info_dev holds `batch` int32.  One queue

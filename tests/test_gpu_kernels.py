@@ -447,6 +447,108 @@ def test_potrf_rows_batched_matches_single(dev, dt, tol, n, batch, m):
         assert got[1] > 0 and all(g == 0 for j, g in enumerate(got) if j != 1)
 
 
+@pytest.mark.parametrize("n,ns,q", [(700, 50, 2), (5632, 130, 2)])
+def test_block_posterior_solve_stage_on_the_idle_context_queue(dev, n, ns, q):
+    """cimrgp_solve_queue: the solve stage of block i on the look-ahead context's idle queue, beside the front end and
+    first panels of block i+1, over TWO rotating buffer sets with no ordering by the caller other than its own reads:
+    bit for bit the one-stream results (small n: the factorisation itself does not use the context)."""
+    tdt = torch.float64
+    nblocks = 5
+    rng = np.random.default_rng(n + 1)
+    blocks = []
+    for b in range(nblocks):
+        x = np.sort(rng.uniform(-2.0, 2.0, size=(n, 1)), axis=0)
+        y = np.stack([np.cos(3 * x[:, 0] + c + b) for c in range(q)], axis=1) + 0.1 * rng.normal(size=(n, q))
+        xs = rng.uniform(-2.0, 2.0, size=(ns, 1))
+        blocks.append(tuple(dev.to_device(a, tdt, "cuda") for a in (x, y, xs)))
+    ell, sf2, noise = 0.05, 1.1, 0.02
+
+    def buffers():
+        return dict(kbuf=dev.alloc_matrix(n, n, tdt, "cuda"), wbuf=dev.alloc_matrix(ns + q, n, tdt, "cuda"),
+                    ws=dev.potrf_workspace(n, tdt, "cuda"), info=torch.zeros(1, dtype=torch.int32, device="cuda"),
+                    alpha=torch.zeros((n, q), dtype=tdt, device="cuda"), z=torch.zeros((n, q), dtype=tdt, device="cuda"),
+                    scratch=torch.empty(2 * q * n, dtype=tdt, device="cuda"))
+    means = [torch.zeros((ns, q), dtype=tdt, device="cuda") for _ in range(2 * nblocks)]
+    vars_ = [torch.zeros(ns, dtype=tdt, device="cuda") for _ in range(2 * nblocks)]
+    bs = buffers()
+    for i, (xd, yd, xsd) in enumerate(blocks):
+        dev.block_posterior(xd, yd, xsd, ell, sf2, noise, bs["kbuf"], bs["wbuf"], bs["ws"], bs["info"], bs["alpha"], bs["z"],
+                            means[i], vars_[i], scratch=bs["scratch"])
+    torch.cuda.synchronize()
+    cur = torch.cuda.current_stream()
+    sq = dev.solve_queue(cur)
+    assert sq.cuda_stream != cur.cuda_stream
+    sets = [buffers(), buffers()]
+    for i, (xd, yd, xsd) in enumerate(blocks):
+        b = sets[i % 2]
+        dev.block_posterior(xd, yd, xsd, ell, sf2, noise, b["kbuf"], b["wbuf"], b["ws"], b["info"], b["alpha"], b["z"],
+                            means[nblocks + i], vars_[nblocks + i], scratch=b["scratch"], streams=(cur, cur, sq))
+    torch.cuda.synchronize()
+    for i in range(nblocks):
+        assert torch.equal(means[i], means[nblocks + i]) and torch.equal(vars_[i], vars_[nblocks + i])
+    assert all(int(b["info"].item()) == 0 for b in sets)
+
+
+@pytest.mark.parametrize("n,ns,q", [(700, 50, 2), (5632, 130, 2)])
+def test_block_posterior_staged_pipeline_matches_the_one_stream_call(dev, n, ns, q):
+    """cimrgp_block_posterior_staged: independent blocks pipelined over three streams and three rotating buffer sets (front
+    end of block i+1 and solve of block i-1 beside the factorisation of block i) give, block by block, bit for bit what
+    the one-stream call gives."""
+    tdt = torch.float64
+    nblocks, nsets = 5, 3
+    rng = np.random.default_rng(n)
+    blocks = []
+    for b in range(nblocks):
+        x = np.sort(rng.uniform(-2.0, 2.0, size=(n, 1)), axis=0)
+        y = np.stack([np.sin(3 * x[:, 0] + c + b) for c in range(q)], axis=1) + 0.1 * rng.normal(size=(n, q))
+        xs = rng.uniform(-2.0, 2.0, size=(ns, 1))
+        blocks.append(tuple(dev.to_device(a, tdt, "cuda") for a in (x, y, xs)))
+    ell, sf2, noise = 0.05, 1.1, 0.02
+
+    def buffers():
+        return dict(kbuf=dev.alloc_matrix(n, n, tdt, "cuda"), wbuf=dev.alloc_matrix(ns + q, n, tdt, "cuda"),
+                    ws=dev.potrf_workspace(n, tdt, "cuda"), info=torch.zeros(1, dtype=torch.int32, device="cuda"),
+                    alpha=torch.zeros((n, q), dtype=tdt, device="cuda"), z=torch.zeros((n, q), dtype=tdt, device="cuda"),
+                    scratch=torch.empty(2 * q * n, dtype=tdt, device="cuda"))
+    # reference: one stream, one buffer set
+    ref = []
+    bs = buffers()
+    for (xd, yd, xsd) in blocks:
+        mean = torch.zeros((ns, q), dtype=tdt, device="cuda")
+        var = torch.zeros(ns, dtype=tdt, device="cuda")
+        dev.block_posterior(xd, yd, xsd, ell, sf2, noise, bs["kbuf"], bs["wbuf"], bs["ws"], bs["info"], bs["alpha"], bs["z"], mean, var,
+                            scratch=bs["scratch"])
+        assert int(bs["info"].item()) == 0
+        ref.append((mean, var, bs["alpha"].clone()))
+    torch.cuda.synchronize()
+    # pipelined
+    sets = [buffers() for _ in range(nsets)]
+    streams = tuple(torch.cuda.Stream() for _ in range(3))
+    done = [None] * nsets
+    got = []
+    for i, (xd, yd, xsd) in enumerate(blocks):
+        s = i % nsets
+        if done[s] is not None:
+            streams[0].wait_event(done[s])                   # the set's last reader
+            with torch.cuda.stream(streams[2]):
+                got[i - nsets] = got[i - nsets][:2] + (sets[s]["alpha"].clone(),)
+            done[s] = torch.cuda.Event(); done[s].record(streams[2])
+            streams[0].wait_event(done[s])
+        mean = torch.zeros((ns, q), dtype=tdt, device="cuda")
+        var = torch.zeros(ns, dtype=tdt, device="cuda")
+        streams[0].wait_stream(torch.cuda.current_stream())  # the zero fills above
+        b = sets[s]
+        dev.block_posterior(xd, yd, xsd, ell, sf2, noise, b["kbuf"], b["wbuf"], b["ws"], b["info"], b["alpha"], b["z"], mean, var,
+                            scratch=b["scratch"], streams=streams)
+        done[s] = torch.cuda.Event(); done[s].record(streams[2])
+        got.append((mean, var, None))
+    torch.cuda.synchronize()
+    for i in range(nblocks):
+        alpha = got[i][2] if got[i][2] is not None else sets[i % nsets]["alpha"]
+        assert torch.equal(got[i][0], ref[i][0]) and torch.equal(got[i][1], ref[i][1]) and torch.equal(alpha, ref[i][2])
+    assert all(int(b["info"].item()) == 0 for b in sets)
+
+
 @pytest.mark.parametrize("n,ns,q,d", [(300, 70, 2, 2), (1100, 130, 3, 1), (5377, 70, 2, 1), (6000, 260, 1, 2)])
 def test_block_posterior_one_call_matches_the_separate_calls_and_the_oracle(dev, n, ns, q, d):
     """cimrgp_block_posterior: Gram, factorisation with the cross-Gram rows and the targets carried, backward solve,
