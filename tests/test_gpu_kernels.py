@@ -510,20 +510,24 @@ def test_block_posterior_staged_pipeline_matches_the_one_stream_call(dev, n, ns,
                     ws=dev.potrf_workspace(n, tdt, "cuda"), info=torch.zeros(1, dtype=torch.int32, device="cuda"),
                     alpha=torch.zeros((n, q), dtype=tdt, device="cuda"), z=torch.zeros((n, q), dtype=tdt, device="cuda"),
                     scratch=torch.empty(2 * q * n, dtype=tdt, device="cuda"))
-    # reference: one stream, one buffer set
+    # reference: one stream -- the pipelined run's factorisation stream: the look-ahead schedule (and with it the last
+    # bits of L) belongs to the stream's context -- and one buffer set
+    streams = tuple(torch.cuda.Stream() for _ in range(3))
     ref = []
     bs = buffers()
     for (xd, yd, xsd) in blocks:
         mean = torch.zeros((ns, q), dtype=tdt, device="cuda")
         var = torch.zeros(ns, dtype=tdt, device="cuda")
-        dev.block_posterior(xd, yd, xsd, ell, sf2, noise, bs["kbuf"], bs["wbuf"], bs["ws"], bs["info"], bs["alpha"], bs["z"], mean, var,
-                            scratch=bs["scratch"])
+        torch.cuda.synchronize()
+        with torch.cuda.stream(streams[1]):
+            dev.block_posterior(xd, yd, xsd, ell, sf2, noise, bs["kbuf"], bs["wbuf"], bs["ws"], bs["info"], bs["alpha"], bs["z"], mean, var,
+                                scratch=bs["scratch"])
+        torch.cuda.synchronize()
         assert int(bs["info"].item()) == 0
         ref.append((mean, var, bs["alpha"].clone()))
     torch.cuda.synchronize()
     # pipelined
     sets = [buffers() for _ in range(nsets)]
-    streams = tuple(torch.cuda.Stream() for _ in range(3))
     done = [None] * nsets
     got = []
     for i, (xd, yd, xsd) in enumerate(blocks):
