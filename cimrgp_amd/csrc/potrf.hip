@@ -2570,9 +2570,14 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
                     rcr = gemm_nt_sub<T>(b + r1 + rn, ldb, b + r0, ldb, k + (r1 + rn) * ld + r0, ld, m128, nfar, (int)rw, false, sf, gb);
                     if (rcr) return rcr;
                     if (m > m128) {
+                        // On the rows' CHAIN queue (round 4), not behind the persistent launch: the far updates of the
+                        // 128-row tiles run back to back on `sf` and are the critical path of this phase; this thin
+                        // launch (240 workgroups for 2 rows, 17-65 us when the units are busy, plus a queue gap)
+                        // took a fifth of that queue's time.  The thin rows are independent of the others, and on `sq`
+                        // the next panel's step -- their only reader -- follows in queue order.
                         GemmBatch g0; g0.pers = 0;
                         rcr = gemm_nt_sub<T>(b + m128 * ldb + r1 + rn, ldb, b + m128 * ldb + r0, ldb, k + (r1 + rn) * ld + r0, ld,
-                                             m - m128, nfar, (int)rw, false, sf, g0);
+                                             m - m128, nfar, (int)rw, false, sq, g0);
                     }
                 } else {
                     rcr = gemm_nt_sub<T>(b + r1 + rn, ldb, b + r0, ldb, k + (r1 + rn) * ld + r0, ld, m, nfar, (int)rw, false, sf);
