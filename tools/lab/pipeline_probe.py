@@ -57,3 +57,27 @@ run("staged, front = factor = s1, solve = cimrgp_solve_queue(s1)", (s1, s1, sq))
 cur = torch.cuda.current_stream()
 sq0 = dev.solve_queue(cur)
 run("staged, default stream, solve = cimrgp_solve_queue(default)", (cur, cur, sq0))
+
+# whole calls alternating over K caller streams (K look-ahead contexts): independent blocks in flight together
+def run_multi(tag, nstreams, steps=16, staged=False):
+    ss = [torch.cuda.Stream() for _ in range(nstreams)]
+    bsets = sets + [make_set() for _ in range(max(0, 2 * nstreams - len(sets)))]
+    sqs = [dev.solve_queue(s) for s in ss] if staged else None
+    def step(i):
+        k = i % nstreams
+        b = bsets[i % (2 * nstreams)] if staged else bsets[k]
+        with torch.cuda.stream(ss[k]):
+            dev.block_posterior(xd, yd, xsd, 0.1, 1.0, 0.01, b["kbuf"], b["wbuf"], b["ws"], b["info"], b["alpha"], b["z"], b["mean"], b["var"],
+                                scratch=b["scratch"], streams=(ss[k], ss[k], sqs[k]) if staged else None)
+    for i in range(2 * nstreams * 2): step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps): step(i)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    print("%-60s %.3f ms/step  %.1f /s" % (tag, ms, 1e3 / ms), flush=True)
+
+run_multi("2 caller streams, whole calls alternating", 2)
+run_multi("3 caller streams, whole calls alternating", 3)
+run_multi("4 caller streams, whole calls alternating", 4)
+run_multi("2 caller streams, staged (solve on each context's queue)", 2, staged=True)
