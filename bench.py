@@ -607,6 +607,10 @@ def main():
                     out["roofline"]["sustained_clock_ghz"] = clk
                     out["roofline"]["peak_at_sustained_clock"] = peak * clk / 2.4
                     out["roofline"]["frac_of_sustained_peak"] = achieved / (peak * clk / 2.4)
+                    out["roofline"]["sustained_clock_note"] = ("GRBM_GUI_ACTIVE / 8 / traced duration under-reads (XCDs that finish early stop "
+                                                               "counting): a register-only v_mfma_f64 loop sustains 0.99 of the nominal "
+                                                               "peak on this part (tools/lab/mfma_loop.hip, HISTORY.md round 4) -- `frac` "
+                                                               "against the nominal peak is the figure to judge")
                 out["roofline"]["traffic"] = fp["traffic_bytes_per_launch"]
                 out["roofline"]["traffic_unit"] = ("bytes/launch (PMC upper bound: 2*FETCH_SIZE + WRITE_SIZE, separate passes; "
                                                    "%s, commit %s)" % (fp["file"], fp["commit"]))
