@@ -209,6 +209,66 @@ static void run_classic(const char* what, const double* A, const double* B, doub
     printf("%-78s grid %4d x %d waves: %8.3f ms  %6.2f TF/s\n", what, grid, WR * WC, best, flop / best / 1e9);
 }
 
+// FP32 register-only loops: does the 16x16x4 form (32 cycles each) issue back to back from two waves per SIMD?  And the
+// 32x32x2 form (64 cycles, the same flops per cycle)?
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+template <int FORM, int WAVES>
+__global__ __launch_bounds__(WAVES * 64)
+void k_f32(float* __restrict__ out, int iters)
+{
+    const int tid = threadIdx.x;
+    float a = 1.0f + tid * 1e-6f, b = 1.0f - tid * 1e-6f;
+    float sum = 0;
+    if (FORM == 0) {
+        f4 acc[8];
+        for (int i = 0; i < 8; ++i) acc[i] = f4{0, 0, 0, 0};
+#pragma unroll 1
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+            asm volatile("" : "+v"(a));
+        }
+        for (int i = 0; i < 8; ++i) for (int r = 0; r < 4; ++r) sum += acc[i][r];
+    } else {
+        f16v acc[4];
+        for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0;
+#pragma unroll 1
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+            asm volatile("" : "+v"(a));
+        }
+        for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) sum += acc[i][r];
+    }
+    out[(size_t)blockIdx.x * WAVES * 64 + tid] = sum;
+}
+
+template <int FORM, int WAVES>
+static void run_f32(const char* what, float* out, int iters)
+{
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k_f32<FORM, WAVES>), dim3(256), dim3(WAVES * 64), 0, 0, out, iters);
+    CHECK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int rep = 0; rep < 5; ++rep) {
+        CHECK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL((k_f32<FORM, WAVES>), dim3(256), dim3(WAVES * 64), 0, 0, out, iters);
+        CHECK(hipEventRecord(e1, 0));
+        CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    // per iteration and wave: FORM 0: 32 x (16*16*4*2) flop, FORM 1: 16 x (32*32*2*2)
+    const double flop = 256.0 * WAVES * iters * (FORM == 0 ? 32 * 2048.0 : 16 * 4096.0);
+    printf("%-78s grid  256 x %d waves: %8.3f ms  %6.2f TF/s\n", what, WAVES, best, flop / best / 1e9);
+}
+
 int main()
 {
     double *A, *B, *out;
@@ -240,5 +300,10 @@ int main()
     run_classic<1, 2, 2, 1>("classic: 2 waves of 64x32 (64x64 tile), 4 workgroups per CU", A, B, out, 1024, chunks);
     run_classic<2, 2, 4, 1>("classic: 4 waves of 64x64 (128x128 tile)", A, B, out, 256, chunks);
     run_classic<2, 2, 4, 2>("classic: 4 waves of 64x64 (128x128 tile), 2 chunks per barrier", A, B, out, 256, chunks);
+    run_f32<0, 4>("FP32 registers only, v_mfma_f32_16x16x4, 4 waves (1 per SIMD)", (float*)out, 20000);
+    run_f32<0, 8>("FP32 registers only, v_mfma_f32_16x16x4, 8 waves (2 per SIMD)", (float*)out, 20000);
+    run_f32<0, 16>("FP32 registers only, v_mfma_f32_16x16x4, 16 waves (4 per SIMD)", (float*)out, 20000);
+    run_f32<1, 4>("FP32 registers only, v_mfma_f32_32x32x2, 4 waves (1 per SIMD)", (float*)out, 20000);
+    run_f32<1, 8>("FP32 registers only, v_mfma_f32_32x32x2, 8 waves (2 per SIMD)", (float*)out, 20000);
     return 0;
 }
