@@ -246,6 +246,27 @@ def test_potrs(dev, dt, tol, n, q):
     assert _relerr(rhs.double().cpu().numpy(), fit["alpha"]) < tol
 
 
+@pytest.mark.parametrize("dt,tol", [("f64", 1e-9), ("f32", 3e-3)])
+@pytest.mark.parametrize("n,m", [(256, 1), (512, 15), (768, 16), (1024, 17), (1280, 129), (1300, 31), (2048, 2050)])
+def test_trsm_rows_one_launch_per_panel(dev, dt, tol, n, m):
+    """The rows' one-launch panel step (k_rows_step: 16 rows per workgroup, previous panel's update fused with the 256-wide
+    solve) through cimrgp_trsm_rows: row counts around the 16-row workgroup, one to eight full panels, a ragged last
+    panel (which keeps the two-launch form behind a fused chain), both precisions, against the oracle's triangular solve."""
+    x, _ = _data(n, 2, seed=n + m)
+    ell, sf2, noise = 0.5, 1.2, 0.05
+    tdt = getattr(torch, TDT[dt])
+    xd, kbuf, ws, info = _factor(dev, x, ell, sf2, noise, tdt)
+    assert int(info.item()) == 0
+    rng = np.random.default_rng(n * 7 + m)
+    b = rng.normal(size=(m, n))
+    w = dev.alloc_matrix(m, n, tdt, "cuda")
+    w[:m, :n] = dev.to_device(b, tdt, "cuda")
+    dev.trsm_rows(kbuf, n, ws, w, m)
+    lref, _ = oracle.potrf_lower(oracle.rbf_gram(x, None, ell, sf2, noise))
+    ref = sla.solve_triangular(lref, b.T, lower=True).T
+    assert _relerr(w[:m, :n].double().cpu().numpy(), ref) < tol
+
+
 @pytest.mark.parametrize("n,m", [(64, 5), (257, 130), (700, 64), (512, 1000), (2500, 70), (3072, 33)])
 def test_trsm_rows_f64(dev, n, m):
     x, _ = _data(n, 2, seed=n)
