@@ -415,7 +415,7 @@ def test_hip_posterior_agrees_with_scikit_learn(dev, golden_dir):
 
 
 @pytest.mark.parametrize("dt,tol", [("f64", 1e-10), ("f32", 5e-4)])
-@pytest.mark.parametrize("n,batch,m", [(1, 2, 0), (130, 3, 2), (1000, 4, 3), (2049, 2, 0)])
+@pytest.mark.parametrize("n,batch,m", [(1, 2, 0), (130, 3, 2), (1000, 4, 3), (2049, 2, 0), (1024, 32, 2), (2048, 16, 3), (1300, 24, 2)])
 def test_potrf_rows_batched_matches_single(dev, dt, tol, n, batch, m):
     """``batch`` equal-sized factorisations in the same launches (blocks of one layer): each must equal
     LAPACK on its own matrix, carried rows and backward solve included; a non-PD member reports its own
