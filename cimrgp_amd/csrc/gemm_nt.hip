@@ -404,6 +404,83 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
 #undef PERS_GLOAD
 }
 
+// ---------------------------------------------------------------------------
+// C[m x N] -= A[m x K] B[N x K]^T for a FEW rows (m <= 4: the q carried target rows of a fit, the rows left over from
+// the 128-row tiles of a far update).  A matrix-core tile for 2 rows wastes the tile and, worse, its latency-bound
+// workgroups read B at 0.75 TB/s (a layer of 128 blocks of 2048 spent 4.4 of its 11.8 ms here).  This is a
+// matrix-vector product: one wave per row of B (coalesced 32 bytes per lane per 2 KB), the rows of A in registers,
+// a fixed-order butterfly reduction; eight rows of B in flight per wave.  Memory-bound on B, read once.
+// ---------------------------------------------------------------------------
+constexpr int THIN_RPW = 8;        // rows of B per wave
+constexpr int THIN_MAXM = 4;       // (5-8 rows: the register budget of eight rows in flight does not hold; those keep the tile kernel)
+template <typename T, int M>
+__global__ __launch_bounds__(256)
+void k_thin_update(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb,
+                   int N, int K, int64_t sc, int64_t sa, int64_t sb)
+{
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    constexpr int EPL = 32 / (int)sizeof(T);          // elements per lane and chunk (32 bytes)
+    constexpr int CH = 64 * EPL;                      // elements per chunk: 256 doubles / 512 floats
+    C += (int64_t)blockIdx.y * sc;
+    A += (int64_t)blockIdx.y * sa;
+    B += (int64_t)blockIdx.y * sb;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = ((int)blockIdx.x * 4 + wave) * THIN_RPW;
+    if (n0 >= N) return;
+    T acc[THIN_RPW][M];
+#pragma unroll
+    for (int i = 0; i < THIN_RPW; ++i)
+#pragma unroll
+        for (int r = 0; r < M; ++r) acc[i][r] = (T)0;
+    for (int kc = 0; kc < K; kc += CH) {
+        const int ke = kc + lane * EPL;
+        const bool live = ke < K;                     // K is a multiple of 16 bytes (the callers' leading dimensions are)
+        T av[M][EPL];
+#pragma unroll
+        for (int r = 0; r < M; ++r) {
+            union { v4u v[2]; T t[EPL]; } u;
+            u.v[0] = live ? *reinterpret_cast<const v4u*>(A + (int64_t)r * lda + ke) : v4u{0, 0, 0, 0};
+            u.v[1] = (live && ke + EPL / 2 < K) ? *reinterpret_cast<const v4u*>(A + (int64_t)r * lda + ke + EPL / 2) : v4u{0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) av[r][e] = u.t[e];
+        }
+        union { v4u v[2]; T t[EPL]; } bv[THIN_RPW];
+#pragma unroll
+        for (int i = 0; i < THIN_RPW; ++i) {
+            const int n = min(n0 + i, N - 1);         // rows past the end: a valid row, never stored
+            const T* bp = B + (int64_t)n * ldb + ke;
+            bv[i].v[0] = live ? *reinterpret_cast<const v4u*>(bp) : v4u{0, 0, 0, 0};
+            bv[i].v[1] = (live && ke + EPL / 2 < K) ? *reinterpret_cast<const v4u*>(bp + EPL / 2) : v4u{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int i = 0; i < THIN_RPW; ++i)
+#pragma unroll
+            for (int r = 0; r < M; ++r)
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) acc[i][r] += av[r][e] * bv[i].t[e];
+    }
+#pragma unroll
+    for (int i = 0; i < THIN_RPW; ++i)
+#pragma unroll
+        for (int r = 0; r < M; ++r) {
+            T v = acc[i][r];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            acc[i][r] = v;
+        }
+    // lane (i, r) = i * M + r writes C[r][n0 + i]
+    if (lane < THIN_RPW * M) {
+        const int i = lane / M, r = lane - i * M;
+        T v = (T)0;
+#pragma unroll
+        for (int ii = 0; ii < THIN_RPW; ++ii)
+#pragma unroll
+            for (int rr = 0; rr < M; ++rr)
+                if (ii == i && rr == r) v = acc[ii][rr];
+        if (n0 + i < N) C[(int64_t)r * ldc + n0 + i] -= v;
+    }
+}
+
 }  // namespace
 
 template <typename T, int W>
@@ -454,6 +531,14 @@ int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t 
     CIMRGP_REQUIRE(aligned16(a) && aligned16(b), fn, "operand base not 16-byte aligned");
     CIMRGP_REQUIRE(lda % Mx<T>::EPC == 0 && ldb % Mx<T>::EPC == 0, fn, "leading dimension not a multiple of 16 bytes");
     CIMRGP_REQUIRE(!lower || m == n, fn, "lower update needs a square C");
+    if (!lower && m <= THIN_MAXM && !bt.skip_first && !bt.head_first && k % Mx<T>::EPC == 0 && aligned16(a) && aligned16(b)) {
+        const dim3 grid((unsigned)((n + 4 * THIN_RPW - 1) / (4 * THIN_RPW)), (unsigned)bt.count);
+#define CIMRGP_THIN(M_) case M_: hipLaunchKernelGGL((k_thin_update<T, M_>), grid, dim3(256), 0, st, c, ldc, a, lda, b, ldb, (int)n, k, bt.sc, bt.sa, bt.sb); break;
+        switch ((int)m) { CIMRGP_THIN(1) CIMRGP_THIN(2) CIMRGP_THIN(3) CIMRGP_THIN(4) }
+#undef CIMRGP_THIN
+        CIMRGP_LAUNCH_CHECK(fn);
+        return 0;
+    }
     // fewer than ~3 workgroups per CU with 128-tiles: use 64-tiles (4x the workgroups, 1/4 the work
     // each; measured sweep of the switch point inside the factorisation at N = 8192:
     // 256/512/768/1024/1536 tiles -> 91.3/93.5/94.2/91.9/90.6 posteriors/s)
