@@ -131,18 +131,20 @@ int block_posterior_typed(const void* x, int64_t n, int d, const void* y, int q,
     using namespace cimrgp;
     const char* fn = "cimrgp_block_posterior";
     T* wt = (T*)w;
+    int dev_id = 0;                                   // the events below belong to the device they were created on
+    if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 16) dev_id = 0;
     // `to` continues where `from` stands now (an event that lives until both have passed it)
     auto hand_over = [&](hipStream_t from, hipStream_t to) -> int {
         if (from == to) return 0;
-        // a ring of events created once (a wait captures the record that precedes it: an event may be recorded again
-        // while an earlier wait on it is still queued)
+        // a ring of events per device, created once (a wait captures the record that precedes it: an event may be
+        // recorded again while an earlier wait on it is still queued)
         static std::mutex ring_mutex;
-        static hipEvent_t ring[64] = {};
+        static hipEvent_t ring[16][64] = {};
         static unsigned ring_next = 0;
         hipEvent_t e = nullptr;
         {
             std::lock_guard<std::mutex> guard(ring_mutex);
-            hipEvent_t& slot = ring[ring_next++ % 64];
+            hipEvent_t& slot = ring[dev_id][ring_next++ % 64];
             if (slot == nullptr) {
                 hipError_t e0 = hipEventCreateWithFlags(&slot, hipEventDisableTiming);
                 if (e0 != hipSuccess) { slot = nullptr; return check_hip(e0, fn, "hipEventCreate"); }
@@ -165,12 +167,13 @@ int block_posterior_typed(const void* x, int64_t n, int d, const void* y, int q,
     // whatever the caller enqueues on `st` next -- the front end of the call after this one, on the set that solve
     // stage read -- comes after it.
     static std::mutex last_mutex;
-    static hipStream_t last_st = nullptr, last_solve = nullptr;
-    static hipEvent_t last_event = nullptr;          // created once, recorded behind every separate solve stage
+    struct LastSolve { hipStream_t st = nullptr, solve = nullptr; hipEvent_t event = nullptr; };   // event: created once per device
+    static LastSolve last_of[16];
+    LastSolve& last = last_of[dev_id];
     if (!rc && s_solve != st) {
         std::lock_guard<std::mutex> guard(last_mutex);
-        if (last_event != nullptr && last_st == st && last_solve == s_solve)
-            rc = check_hip(hipStreamWaitEvent(st, last_event, 0), fn, "hipStreamWaitEvent");
+        if (last.event != nullptr && last.st == st && last.solve == s_solve)
+            rc = check_hip(hipStreamWaitEvent(st, last.event, 0), fn, "hipStreamWaitEvent");
     }
     // z = L^-1 y (the last q carried rows), alpha = L^-T z, mean = W z, var = sf2 - sum W^2 (+ noise)
     if (!rc) rc = rows_to_z_run<T>(wt + ns * ldw, ldw, n, q, (T*)z, (T*)alpha, s_solve);
@@ -179,11 +182,11 @@ int block_posterior_typed(const void* x, int64_t n, int d, const void* y, int q,
                                                    (T*)mean, (T*)var, accumulate, s_solve, 1, nullptr, 0);
     if (!rc && s_solve != st) {
         std::lock_guard<std::mutex> guard(last_mutex);
-        if (last_event == nullptr && hipEventCreateWithFlags(&last_event, hipEventDisableTiming) != hipSuccess) last_event = nullptr;
-        if (last_event != nullptr) {
-            rc = check_hip(hipEventRecord(last_event, s_solve), fn, "hipEventRecord");
-            last_st = st;
-            last_solve = s_solve;
+        if (last.event == nullptr && hipEventCreateWithFlags(&last.event, hipEventDisableTiming) != hipSuccess) last.event = nullptr;
+        if (last.event != nullptr) {
+            rc = check_hip(hipEventRecord(last.event, s_solve), fn, "hipEventRecord");
+            last.st = st;
+            last.solve = s_solve;
         }
     }
     return rc;
