@@ -21,7 +21,8 @@ static __device__ __forceinline__ double slot(const v4u* v, int s)
 
 // V: 0 registers only; 1 + LDS fragment reads (b128, both operands); 2 + LDS writes and a barrier per chunk (double buffer);
 //    3 + global loads of both operands (the classic loop); 4 A straight from global memory to registers, B through LDS;
-//    5 like 3 with 8-byte fragment reads (ds_read_b64, the k order of the shipped kernels)
+//    5 like 3 with 8-byte fragment reads (ds_read_b64, the k order of the shipped kernels); 6 = 2 without the barrier (timing only);
+//    7 = 1 with a barrier per chunk and no LDS writes
 template <int V, int WAVES>
 __global__ __launch_bounds__(WAVES * 64)
 void k_loop(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ out, int chunks, int lda)
@@ -62,12 +63,12 @@ void k_loop(const double* __restrict__ A, const double* __restrict__ B, double* 
             const int buf = c & 1;
             const unsigned char* abase = (V >= 2) ? abase0 + buf * 2 * 128 * LROW : abase0;
             const unsigned char* bbase = (V >= 2) ? bbase0 + buf * 2 * 128 * LROW : bbase0;
-            if (V >= 2) {
+            if (V >= 2 && V != 7) {
                 // next chunk into the other buffer
                 unsigned char* as = smem + (buf ^ 1) * 2 * 128 * LROW, *bs = as + 128 * LROW;
                 for (int p = 0; p < NPASS; ++p) {
-                    if (V != 4) *reinterpret_cast<v4u*>(as + (sr + RPP * p) * LROW + sc * 16) = (V == 2) ? rdummy : ra[p];
-                    *reinterpret_cast<v4u*>(bs + (sr + RPP * p) * LROW + sc * 16) = (V == 2) ? rdummy : rb[p];
+                    if (V != 4) *reinterpret_cast<v4u*>(as + (sr + RPP * p) * LROW + sc * 16) = (V == 2 || V == 6) ? rdummy : ra[p];
+                    *reinterpret_cast<v4u*>(bs + (sr + RPP * p) * LROW + sc * 16) = (V == 2 || V == 6) ? rdummy : rb[p];
                 }
             }
             if (V == 3 || V == 5) for (int p = 0; p < NPASS; ++p) {
@@ -104,7 +105,7 @@ void k_loop(const double* __restrict__ A, const double* __restrict__ B, double* 
                     for (int i = 0; i < MI; ++i) for (int j = 0; j < NI; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(slot(fa[i], s), slot(fb[j], s), acc[i][j], 0, 0, 0);
             }
-            if (V >= 2) __syncthreads();
+            if (V >= 2 && V != 6) __syncthreads();
             if (V == 0) asm volatile("" : "+v"(rdummy));
         }
     }
@@ -293,6 +294,9 @@ int main()
     run<5, 8>("5 ... 8 waves of 64x32", A, B, out, 256, chunks);
     run<4, 4>("4 A straight from global memory, B through LDS", A, B, out, 256, chunks);
     run<4, 4>("4 ... 2 workgroups per CU", A, B, out, 512, chunks);
+    run<4, 8>("4 ... 8 waves of 64x32: A straight from global memory, B through LDS", A, B, out, 256, chunks);
+    run<6, 8>("6 LDS writes, NO barrier (timing only), 8 waves of 64x32", A, B, out, 256, chunks);
+    run<7, 8>("7 barrier per chunk, NO LDS writes, 8 waves of 64x32", A, B, out, 256, chunks);
     run_classic<2, 4, 2, 1>("classic: 8 waves of 64x32 (128x128 tile), 1 chunk per barrier", A, B, out, 256, chunks);
     run_classic<2, 4, 2, 2>("classic: 8 waves of 64x32 (128x128 tile), 2 chunks per barrier", A, B, out, 256, chunks);
     run_classic<2, 2, 2, 1>("classic: 4 waves of 64x32 (128x64 tile), 2 workgroups per CU", A, B, out, 512, chunks);
