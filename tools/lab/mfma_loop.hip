@@ -270,6 +270,85 @@ static void run_f32(const char* what, float* out, int iters)
     printf("%-78s grid  256 x %d waves: %8.3f ms  %6.2f TF/s\n", what, WAVES, best, flop / best / 1e9);
 }
 
+// The classic eight-wave loop with the operands loaded STRAIGHT INTO LDS (global_load_lds_dwordx4: no staging registers, no
+// ds_write): unpadded 128-byte rows, 16-byte pieces XOR-swizzled by (row >> 1) & 7 so that the 8-byte fragment reads stay
+// conflict-free; three stage buffers (two stages of loads in flight).
+__global__ __launch_bounds__(512)
+void k_ldsdma(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ out, int chunks, int lda)
+{
+    constexpr int STAGE = 256 * 128;                      // [A rows 0..127 ; B rows 0..127] x 128 bytes
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int frow = lane & 15, fslot = lane >> 4;
+    acc_t acc[4][2];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+    const double* ag = A + (size_t)(blockIdx.x % 32) * 128 * lda;
+    const double* bg = B + (size_t)(blockIdx.x % 32) * 128 * lda;
+    // this lane's four loads of a stage: LDS kilobyte (wave * 4 + q), row 8 (wave * 4 + q) + (lane >> 3), physical piece lane & 7
+    const double* gsrc[4];
+    for (int q = 0; q < 4; ++q) {
+        const int r = 8 * (wave * 4 + q) + (lane >> 3), pp = lane & 7;
+        const int p = pp ^ ((r >> 1) & 7);
+        gsrc[q] = (r < 128 ? ag + (size_t)r * lda : bg + (size_t)(r - 128) * lda) + p * 2;
+    }
+    auto load_stage = [&](int buf, int kcol) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_global_load_lds((const void*)(gsrc[q] + kcol), (__attribute__((address_space(3))) void*)(smem + buf * STAGE + (wave * 4 + q) * 1024), 16, 0, 0);
+    };
+    // fragment offsets inside a row for the four k-steps of a stage
+    unsigned off[4];
+    const int key = (frow >> 1) & 7;
+    for (int sx = 0; sx < 4; ++sx) off[sx] = (unsigned)((((2 * sx + (fslot >> 1)) ^ key) * 16) + (fslot & 1) * 8);
+    const unsigned arow = (unsigned)((wr * 64 + frow) * 128), brow = (unsigned)((128 + wc * 32 + frow) * 128);
+    load_stage(0, 0);
+    load_stage(1, 16);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __syncthreads();
+#pragma unroll 1
+    for (int c3 = 0; c3 < chunks; c3 += 3) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int c = c3 + u;
+            load_stage((u + 2) % 3, ((c + 2) & 15) * 16);
+            const unsigned char* sb = smem + u * STAGE;
+#pragma unroll
+            for (int sx = 0; sx < 4; ++sx) {
+                double a[4], b[2];
+                for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const double*>(sb + arow + i * 16 * 128 + off[sx]);
+                for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const double*>(sb + brow + j * 16 * 128 + off[sx]);
+                for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");        // the stage after this one has landed (its successor may still fly)
+            __syncthreads();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    double sum = 0;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 4; ++r) sum += acc[i][j][r];
+    out[(size_t)blockIdx.x * 512 + tid] = sum;
+}
+
+static void run_ldsdma(const double* A, const double* B, double* out, int chunks)
+{
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_ldsdma, dim3(256), dim3(512), 0, 0, A, B, out, chunks, 256);
+    CHECK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int rep = 0; rep < 5; ++rep) {
+        CHECK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k_ldsdma, dim3(256), dim3(512), 0, 0, A, B, out, chunks, 256);
+        CHECK(hipEventRecord(e1, 0));
+        CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    const double flop = 256.0 * 8 * chunks * 8.0 * 4 * 2048.0;
+    printf("%-78s grid  256 x 8 waves: %8.3f ms  %6.2f TF/s\n", "8 classic loop, operands straight into LDS (global_load_lds_dwordx4), 3 buffers", best, flop / best / 1e9);
+}
+
 int main()
 {
     double *A, *B, *out;
@@ -295,6 +374,7 @@ int main()
     run<4, 4>("4 A straight from global memory, B through LDS", A, B, out, 256, chunks);
     run<4, 4>("4 ... 2 workgroups per CU", A, B, out, 512, chunks);
     run<4, 8>("4 ... 8 waves of 64x32: A straight from global memory, B through LDS", A, B, out, 256, chunks);
+    run_ldsdma(A, B, out, chunks);
     run<6, 8>("6 LDS writes, NO barrier (timing only), 8 waves of 64x32", A, B, out, 256, chunks);
     run<7, 8>("7 barrier per chunk, NO LDS writes, 8 waves of 64x32", A, B, out, 256, chunks);
     run_classic<2, 4, 2, 1>("classic: 8 waves of 64x32 (128x128 tile), 1 chunk per barrier", A, B, out, 256, chunks);
