@@ -510,6 +510,48 @@ def test_block_posterior_solve_stage_on_the_idle_context_queue(dev, n, ns, q):
     assert all(int(b["info"].item()) == 0 for b in sets)
 
 
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+@pytest.mark.parametrize("n,ns", [(300, 0), (6144, 0), (6144, 37)])
+def test_block_posterior_staged_edge_cases(dev, dt, n, ns):
+    """The staged call without test points (ns = 0: fit only), with accumulation into mean / variance, in both
+    precisions: bit for bit the one-stream call; equal streams ARE that call."""
+    tdt = getattr(torch, TDT[dt])
+    q = 2
+    rng = np.random.default_rng(n + ns)
+    x = np.sort(rng.uniform(-2.0, 2.0, size=(n, 1)), axis=0)
+    y = np.stack([np.sin(3 * x[:, 0] + c) for c in range(q)], axis=1) + 0.1 * rng.normal(size=(n, q))
+    xd, yd = dev.to_device(x, tdt, "cuda"), dev.to_device(y, tdt, "cuda")
+    xsd = dev.to_device(rng.uniform(-2.0, 2.0, size=(ns, 1)), tdt, "cuda") if ns else None
+    ell, sf2, noise = 0.05, 1.1, 0.1
+
+    def run(streams):
+        kbuf = dev.alloc_matrix(n, n, tdt, "cuda")
+        wbuf = dev.alloc_matrix(ns + q, n, tdt, "cuda")
+        ws = dev.potrf_workspace(n, tdt, "cuda")
+        info = torch.zeros(1, dtype=torch.int32, device="cuda")
+        alpha = torch.zeros((n, q), dtype=tdt, device="cuda")
+        z = torch.zeros((n, q), dtype=tdt, device="cuda")
+        mean = torch.full((max(ns, 1), q), 0.5, dtype=tdt, device="cuda")
+        var = torch.full((max(ns, 1),), 0.25, dtype=tdt, device="cuda")
+        torch.cuda.synchronize()
+        dev.block_posterior(xd, yd, xsd, ell, sf2, noise, kbuf, wbuf, ws, info, alpha, z, mean if ns else None, var if ns else None,
+                            add_noise=True, accumulate=True, streams=streams)
+        torch.cuda.synchronize()
+        assert int(info.item()) == 0
+        return torch.tril(kbuf[:n, :n]).clone(), alpha, z, mean, var
+
+    cur = torch.cuda.current_stream()
+    ref = run(None)
+    same = run((cur, cur, cur))
+    piped = run((cur, cur, dev.solve_queue(cur)))
+    for got in (same, piped):
+        assert all(torch.equal(a, b) for a, b in zip(ref, got))
+    if ns:
+        assert float(ref[3].min()) != 0.5 or float(ref[3].max()) != 0.5      # accumulated onto the 0.5 / 0.25 fills
+    fit = oracle.block_fit(x, y, ell, sf2, noise)
+    assert _relerr(ref[1].double().cpu().numpy(), fit["alpha"]) < (1e-8 if dt == "f64" else 5e-3)
+
+
 @pytest.mark.parametrize("n,ns,q", [(700, 50, 2), (5632, 130, 2)])
 def test_block_posterior_staged_pipeline_matches_the_one_stream_call(dev, n, ns, q):
     """cimrgp_block_posterior_staged: independent blocks pipelined over three streams and three rotating buffer sets (front
