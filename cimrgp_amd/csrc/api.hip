@@ -235,8 +235,9 @@ int cimrgp_rbf_cross(int dtype, const void* xa_dev, int64_t na, const void* xb_d
 size_t cimrgp_potrf_workspace_bytes(int dtype, int64_t n)
 {
     if (n <= 0) return 0;
-    const int64_t slabs = (n + 63) / 64, panels = (n + CIMRGP_NB - 1) / CIMRGP_NB;
-    return (size_t)(slabs * 64 * 64 + panels * CIMRGP_NB * CIMRGP_NB) * esize(dtype);
+    const int64_t slabs = (n + 63) / 64, panels = (n + CIMRGP_NB - 1) / CIMRGP_NB, pairs = (n / CIMRGP_NB) / 2;
+    // 64 x 64 inverses, 256 x 256 inverses, off-diagonal blocks of the 512 x 512 inverses (pairs of full panels)
+    return (size_t)(slabs * 64 * 64 + (panels + pairs) * CIMRGP_NB * CIMRGP_NB) * esize(dtype);
 }
 
 int cimrgp_potrf(int dtype, void* k_dev, int64_t n, int64_t ldk, void* workspace_dev, size_t workspace_bytes,

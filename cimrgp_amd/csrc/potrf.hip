@@ -1568,8 +1568,22 @@ template <typename T> struct RowsStep {
 
 template <typename T, bool HAS_PREV>
 __global__ __launch_bounds__(256)
-void k_rows_step(T* __restrict__ P, int64_t ldp, int M, const T* __restrict__ Lrow, int64_t ldl, const T* __restrict__ inv64)
+void k_rows_step(T* __restrict__ P, int64_t ldp, int M, const T* __restrict__ Lrow, int64_t ldl, const T* __restrict__ inv64,
+                 const T* __restrict__ Pprev = nullptr, int64_t ldprev = 0, int b_zero = 0, int ny = 1,
+                 int64_t sp = 0, int64_t sl = 0, int64_t sws = 0, int64_t sprev = 0,
+                 int64_t sp2 = 0, int64_t sl2 = 0, int64_t sws2 = 0)
 {
+    // Pprev: the previous panel's solved rows live elsewhere (row r of this launch at Pprev + r * ldprev) instead of in
+    // the 256 columns left of P; b_zero: B_p = 0 (not read).  blockIdx.y = i + ny * j: problem i of ny with strides
+    // (sp, sl, sws, sprev), inside matrix j of a batch with strides (sp2, sl2, sws2; Pprev moves with sp2).  These
+    // serve the 512-wide inverses of the skinny backward solve (build_invT).
+    {
+        const int yi = (int)blockIdx.y % ny, yj = (int)blockIdx.y / ny;
+        P += (int64_t)yi * sp + (int64_t)yj * sp2;
+        Lrow += (int64_t)yi * sl + (int64_t)yj * sl2;
+        inv64 += (int64_t)yi * sws + (int64_t)yj * sws2;
+        if (Pprev) Pprev += (int64_t)yi * sprev + (int64_t)yj * sp2;
+    }
     using X = Mx<T>;
     using acc_t = typename X::acc_t;
     using RS = RowsStep<T>;
@@ -1591,7 +1605,8 @@ void k_rows_step(T* __restrict__ P, int64_t ldp, int M, const T* __restrict__ Lr
     v4u stg[HAS_PREV ? RS::NCP / 2 : 1];
     const int sr = tid >> 4, st16 = tid & 15;
     if (HAS_PREV) {
-        const T* src = Prow - KPREV + (int64_t)min(sr, mrows - 1) * ldp;    // rows past the end: a valid row's values, never stored
+        // rows past the end: a valid row's values, never stored
+        const T* src = Pprev ? Pprev + (int64_t)(row0 + min(sr, mrows - 1)) * ldprev : Prow - KPREV + (int64_t)min(sr, mrows - 1) * ldp;
 #pragma unroll
         for (int i = 0; i < RS::NCP / 2; ++i) stg[i] = *reinterpret_cast<const v4u*>(src + (i * 16 + st16) * X::EPC);
     }
@@ -1600,7 +1615,7 @@ void k_rows_step(T* __restrict__ P, int64_t ldp, int M, const T* __restrict__ Lr
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            acc[j][r] = Prow[(int64_t)min(X::crow(lane, r), mrows - 1) * ldp + SB * j + ctile];
+            acc[j][r] = b_zero ? (T)0 : Prow[(int64_t)min(X::crow(lane, r), mrows - 1) * ldp + SB * j + ctile];
 
     // right-operand rows of this lane: rows SB j + ctile of the panel's row block of L, and of the inverses
     const T* lp[4];
@@ -2409,6 +2424,22 @@ static int build_invT(const T* kmat, int64_t n, int64_t ld, T* ws, hipStream_t s
     hipLaunchKernelGGL((k_invT_panel<T>), dim3(CIMRGP_NB / TR, (unsigned)npan, nbatch), dim3(256), 0, st,
                        invT, kmat, ld, (int)n, (const T*)ws, bt.sk, bt.sws);
     CIMRGP_LAUNCH_CHECK(fn);
+    // Round 4: the backward solve takes TWO panels per step through the 512 x 512 inverse
+    //     [A 0; B C]^-T = [A^-T  X; 0  C^-T],   X = -A^-T B^T C^-T  (256 x 256, dense),
+    // halving its chain of dependent launches (62 -> 32 at n = 8192: 0.33 -> 0.2 ms).  X is what the carried rows' panel
+    // step computes for the rows of A^-T (already there: invT of the pair's first panel) with a zero right-hand side:
+    // one launch of k_rows_step for all pairs of full panels, behind the inverses (potrs_run: bwd_pairs).
+    const int64_t npairs = (n / CIMRGP_NB) / 2;
+    if (npairs > 0) {
+        T* xbase = invT + npan * (CIMRGP_NB * CIMRGP_NB);
+        const int64_t blk = (int64_t)CIMRGP_NB * CIMRGP_NB;
+        hipLaunchKernelGGL((k_rows_step<T, true>), dim3(CIMRGP_NB / RowsStep<T>::R, (unsigned)(npairs * bt.count)), dim3(256), 0, st,
+                           xbase, (int64_t)CIMRGP_NB, (int)CIMRGP_NB, (const T*)(kmat + (int64_t)CIMRGP_NB * ld), ld,
+                           (const T*)(ws + (CIMRGP_NB / SB) * (SB * SB)), (const T*)invT, (int64_t)CIMRGP_NB, 1, (int)npairs,
+                           blk, 2 * CIMRGP_NB * ld + 2 * CIMRGP_NB, (int64_t)(2 * CIMRGP_NB / SB) * (SB * SB), 2 * blk,
+                           bt.sws, bt.sk, bt.sws);
+        CIMRGP_LAUNCH_CHECK(fn);
+    }
     return 0;
 }
 

@@ -167,7 +167,52 @@ void k_bwd_alpha(const T* __restrict__ invT, int n, const T* __restrict__ work, 
     }
 }
 
+// Round 4: TWO panels per backward step (62 -> 32 dependent launches at n = 8192) through the 512 x 512 inverse
+//     [invT_p  X; 0  invT_p+1]  (X = -A^-T B^T C^-T, built behind the 256 x 256 inverses: potrf.hip, build_invT):
+//   a_p = invT_p w_p + X w_p+1,  a_p+1 = invT_p+1 w_p+1 : one wave per row of the pair, 128 workgroups of 4 rows.
 template <typename T, int Q>
+__global__ __launch_bounds__(256)
+void k_bwd_alpha2(const T* __restrict__ invT, const T* __restrict__ xoff, int n, const T* __restrict__ work, T* __restrict__ out,
+                  int k0, int64_t sws = 0, int64_t sscr = 0)
+{
+    invT += (int64_t)blockIdx.y * sws;
+    xoff += (int64_t)blockIdx.y * sws;
+    work += (int64_t)blockIdx.y * sscr;
+    out += (int64_t)blockIdx.y * sscr;
+    const int lane = threadIdx.x & 63;
+    const int r2 = blockIdx.x * 4 + (threadIdx.x >> 6);          // row of the pair, 0 .. 511
+    const bool top = r2 < PW;
+    const int r = top ? r2 : r2 - PW;
+    const T* rp = invT + (int64_t)(k0 / PW + (top ? 0 : 1)) * (PW * PW) + (int64_t)r * PW + lane * 4;
+    const int wcol = k0 + (top ? 0 : PW) + lane * 4;              // the right-hand side columns this lane multiplies
+    const bool live = lane * 4 + 3 >= r;                          // this lane's columns reach the diagonal or beyond
+    T bv[4], xv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[e] = live ? rp[e] : (T)0;
+    if (top) {
+        const T* xp = xoff + (int64_t)(k0 / (2 * PW)) * (PW * PW) + (int64_t)r * PW + lane * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[e] = xp[e];
+    }
+#pragma unroll
+    for (int c = 0; c < Q; ++c) {
+        T sv = (T)0;
+        if (live) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sv += bv[e] * work[(int64_t)c * n + wcol + e];
+        }
+        if (top) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sv += xv[e] * work[(int64_t)c * n + k0 + PW + lane * 4 + e];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sv += __shfl_xor(sv, off, 64);
+        if (lane == 0) out[(int64_t)c * n + k0 + r2] = sv;
+    }
+}
+
+// PWU = rows of the step: one panel (256) or a pair (512)
+template <typename T, int Q, int PWU = PW>
 __global__ __launch_bounds__(ST)
 void k_bwd_update(const T* __restrict__ L, int64_t ld, int n, T* __restrict__ work, const T* __restrict__ alpha,
                   int k0, int w, int64_t sk = 0, int64_t sscr = 0)
@@ -175,28 +220,29 @@ void k_bwd_update(const T* __restrict__ L, int64_t ld, int n, T* __restrict__ wo
     L += (int64_t)blockIdx.y * sk;
     work += (int64_t)blockIdx.y * sscr;
     alpha += (int64_t)blockIdx.y * sscr;
-    __shared__ T zs[Q][PW];
+    constexpr int RPP = PWU / 16;                                 // rows per part
+    __shared__ T zs[Q][PWU];
     __shared__ T red[16][Q][SB];
     const int tid = threadIdx.x;
-    const int t = tid & 63, part = tid >> 6;                      // 16 row parts of 16
+    const int t = tid & 63, part = tid >> 6;                      // 16 row parts
     const int col = blockIdx.x * SB + t;
-    const int ubeg = part * 16;
-    T lv[16];
+    const int ubeg = part * RPP;
+    T lv[RPP];
     if (col < k0) {
         const T* lp = L + (int64_t)k0 * ld + col;
-        if (w == PW) {
+        if (w == PWU) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) lv[e] = lp[(int64_t)(ubeg + e) * ld];
+            for (int e = 0; e < RPP; ++e) lv[e] = lp[(int64_t)(ubeg + e) * ld];
         } else {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) lv[e] = (ubeg + e < w) ? lp[(int64_t)(ubeg + e) * ld] : (T)0;
+            for (int e = 0; e < RPP; ++e) lv[e] = (ubeg + e < w) ? lp[(int64_t)(ubeg + e) * ld] : (T)0;
         }
     } else {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) lv[e] = (T)0;
+        for (int e = 0; e < RPP; ++e) lv[e] = (T)0;
     }
-    for (int e = tid; e < Q * PW; e += ST) {
-        const int c = e / PW, u = e - c * PW;
+    for (int e = tid; e < Q * PWU; e += ST) {
+        const int c = e / PWU, u = e - c * PWU;
         zs[c][u] = (u < w) ? alpha[(int64_t)c * n + k0 + u] : (T)0;
     }
     __syncthreads();
@@ -204,7 +250,7 @@ void k_bwd_update(const T* __restrict__ L, int64_t ld, int n, T* __restrict__ wo
 #pragma unroll
     for (int c = 0; c < Q; ++c) acc[c] = (T)0;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
+    for (int e = 0; e < RPP; ++e) {
 #pragma unroll
         for (int c = 0; c < Q; ++c)
             acc[c] += lv[e] * zs[c][ubeg + e];
@@ -353,7 +399,9 @@ int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* 
         if (e != hipSuccess) return check_hip(e, fn, "hipMemcpyAsync");
     }   // backward_only: `work` already holds z (RHS-major), put there by the first transpose
     const int64_t last = ((n - 1) / PW) * PW;
-    for (int64_t k0 = last; k0 >= 0; k0 -= PW) {
+    const int64_t npairs = (n / PW) / 2;                           // pairs of full panels: two per step (k_bwd_alpha2)
+    const T* xoff = invT + ((n + PW - 1) / PW) * (PW * PW);
+    for (int64_t k0 = last; k0 >= 2 * npairs * PW; k0 -= PW) {    // what lies behind the pairs: at most two panels, singly
         const int w = (int)((n - k0 < PW) ? (n - k0) : PW);
         const unsigned grid = (unsigned)((k0 + SB - 1) / SB);
         CIMRGP_Q_SWITCH(q, hipLaunchKernelGGL((k_bwd_alpha<T, QQ>), dim3((unsigned)((w + 3) / 4), nbatch), dim3(256), 0, st,
@@ -362,6 +410,18 @@ int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* 
         if (grid) {
             CIMRGP_Q_SWITCH(q, hipLaunchKernelGGL((k_bwd_update<T, QQ>), dim3(grid, nbatch), dim3(ST), 0, st, l, ld, (int)n,
                                                   work, (const T*)res, (int)k0, w, bt.sk, sscr));
+            CIMRGP_LAUNCH_CHECK(fn);
+        }
+    }
+    for (int64_t j = npairs - 1; j >= 0; --j) {
+        const int64_t k0 = 2 * PW * j;
+        const unsigned grid = (unsigned)((k0 + SB - 1) / SB);
+        CIMRGP_Q_SWITCH(q, hipLaunchKernelGGL((k_bwd_alpha2<T, QQ>), dim3(2 * PW / 4, nbatch), dim3(256), 0, st,
+                                              invT, xoff, (int)n, (const T*)work, res, (int)k0, bt.sws, sscr));
+        CIMRGP_LAUNCH_CHECK(fn);
+        if (grid) {
+            CIMRGP_Q_SWITCH(q, hipLaunchKernelGGL((k_bwd_update<T, QQ, 2 * PW>), dim3(grid, nbatch), dim3(ST), 0, st, l, ld, (int)n,
+                                                  work, (const T*)res, (int)k0, 2 * PW, bt.sk, sscr));
             CIMRGP_LAUNCH_CHECK(fn);
         }
     }

@@ -78,7 +78,9 @@ int cimrgp_rbf_cross(int dtype, const void* xa_dev, int64_t na,
  * inverted diagonal block (MFMA), trailing SYRK update (MFMA 16x16x4 f64 /
  * f32) with one-panel look-ahead on an internal second stream.
  * workspace: cimrgp_potrf_workspace_bytes(dtype, n) bytes, keeps the inverted
- * diagonal blocks needed by cimrgp_potrs / cimrgp_trsm_rows afterwards.
+ * diagonal blocks needed by cimrgp_potrs / cimrgp_trsm_rows afterwards (the
+ * 64 x 64 and 256 x 256 inverses and, per pair of full panels, the off-diagonal
+ * block of the 512 x 512 inverse the backward solve steps through).
  * info_dev: one int32, written asynchronously. */
 size_t cimrgp_potrf_workspace_bytes(int dtype, int64_t n);
 int cimrgp_potrf(int dtype, void* k_dev, int64_t n, int64_t ldk,

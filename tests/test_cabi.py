@@ -30,7 +30,9 @@ def test_version_and_workspace_size():
     lib = _lib.load()
     assert lib.cimrgp_version() >= 100
     # 64x64 inverse slabs + 256x256 inverse blocks of the diagonal
-    assert lib.cimrgp_potrf_workspace_bytes(_lib.F64, 8192) == (128 * 64 * 64 + 32 * 256 * 256) * 8
+    # 64 x 64 inverses, 256 x 256 inverses, off-diagonal blocks of the 512 x 512 inverses (one per pair of full panels)
+    assert lib.cimrgp_potrf_workspace_bytes(_lib.F64, 8192) == (128 * 64 * 64 + (32 + 16) * 256 * 256) * 8
+    assert lib.cimrgp_potrf_workspace_bytes(_lib.F32, 700) == (11 * 64 * 64 + (3 + 1) * 256 * 256) * 4
     assert lib.cimrgp_potrf_workspace_bytes(_lib.F32, 65) == (2 * 64 * 64 + 1 * 256 * 256) * 4
     assert lib.cimrgp_potrf_workspace_bytes(_lib.F64, 0) == 0
 
