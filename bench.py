@@ -348,7 +348,7 @@ def main():
     # Its outputs land directly in this rank's slices of the fused [mean (ns_total x q) | var (ns_total)] buffer of
     # the step's one collective.
     # Consecutive steps are INDEPENDENT blocks (the partitions of a layer), so they are pipelined: two buffer sets in
-    # rotation, and the call's last stage -- the latency-bound backward solve and prediction (0.33 ms of 62 small
+    # rotation, and the call's last stage -- the latency-bound backward solve and prediction (0.26 ms of 32 small
     # launches) -- on the look-ahead context's queue that is idle between two factorisations (cimrgp_solve_queue), beside
     # the Gram matrices and first panels of the next step.  (A stream of the bench's own for that stage is a fifth
     # queue for a runtime that serves four: 8.1 -> 10.2 ms per step; tools/lab/pipeline_probe.py.)
