@@ -1574,7 +1574,7 @@ void k_rows_step(T* __restrict__ P, int64_t ldp, int M, const T* __restrict__ Lr
                  int64_t sp2 = 0, int64_t sl2 = 0, int64_t sws2 = 0)
 {
     // Pprev: the previous panel's solved rows live elsewhere (row r of this launch at Pprev + r * ldprev) instead of in
-    // the 256 columns left of P; b_zero: B_p = 0 (not read).  blockIdx.y = i + ny * j: problem i of ny with strides
+    // the 256 columns left of P; b_zero: B_p = 0 (1) or the identity (2), not read.  blockIdx.y = i + ny * j: problem i of ny with strides
     // (sp, sl, sws, sprev), inside matrix j of a batch with strides (sp2, sl2, sws2; Pprev moves with sp2).  These
     // serve the 512-wide inverses of the skinny backward solve (build_invT).
     {
@@ -1615,7 +1615,8 @@ void k_rows_step(T* __restrict__ P, int64_t ldp, int M, const T* __restrict__ Lr
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            acc[j][r] = b_zero ? (T)0 : Prow[(int64_t)min(X::crow(lane, r), mrows - 1) * ldp + SB * j + ctile];
+            acc[j][r] = (b_zero == 0) ? Prow[(int64_t)min(X::crow(lane, r), mrows - 1) * ldp + SB * j + ctile]
+                      : (b_zero == 2 && row0 + X::crow(lane, r) == SB * j + ctile) ? (T)1 : (T)0;
 
     // right-operand rows of this lane: rows SB j + ctile of the panel's row block of L, and of the inverses
     const T* lp[4];
@@ -1748,12 +1749,12 @@ void k_rows_step(T* __restrict__ P, int64_t ldp, int M, const T* __restrict__ Lr
 template <typename T>
 __global__ __launch_bounds__(256)
 void k_invT_panel(T* __restrict__ invT, const T* __restrict__ L, int64_t ld, int n, const T* __restrict__ inv64,
-                  int64_t sk = 0, int64_t sws = 0)
+                  int64_t sk = 0, int64_t sws = 0, int p0 = 0)
 {
     invT += (int64_t)blockIdx.z * sws;
     L += (int64_t)blockIdx.z * sk;
     inv64 += (int64_t)blockIdx.z * sws;
-    const int p = blockIdx.y, strip = blockIdx.x;
+    const int p = p0 + (int)blockIdx.y, strip = blockIdx.x;
     const int k0 = p * CIMRGP_NB;
     const int w = min(CIMRGP_NB, n - k0);
     T* blk = invT + (int64_t)p * (CIMRGP_NB * CIMRGP_NB) + (int64_t)strip * TR * CIMRGP_NB;
@@ -2421,9 +2422,24 @@ static int build_invT(const T* kmat, int64_t n, int64_t ld, T* ws, hipStream_t s
     const int64_t nslab = (n + SB - 1) / SB, npan = (n + CIMRGP_NB - 1) / CIMRGP_NB;
     T* invT = ws + nslab * (SB * SB);
     const unsigned nbatch = (unsigned)bt.count;
-    hipLaunchKernelGGL((k_invT_panel<T>), dim3(CIMRGP_NB / TR, (unsigned)npan, nbatch), dim3(256), 0, st,
-                       invT, kmat, ld, (int)n, (const T*)ws, bt.sk, bt.sws);
-    CIMRGP_LAUNCH_CHECK(fn);
+    // Full panels (round 4): invT_p = I L_pp^-T is the carried rows' panel step applied to the identity -- one launch of
+    // k_rows_step for all of them (16 workgroups per panel, ~12 us) instead of k_invT_panel's four dependent sub-steps
+    // per 32-row strip with their global round trips (40 us at the end of every factorisation); a ragged last panel
+    // keeps k_invT_panel.
+    const int64_t nfull = n / CIMRGP_NB;
+    const int64_t blk = (int64_t)CIMRGP_NB * CIMRGP_NB;
+    if (nfull > 0) {
+        hipLaunchKernelGGL((k_rows_step<T, false>), dim3(CIMRGP_NB / RowsStep<T>::R, (unsigned)(nfull * bt.count)), dim3(256), 0, st,
+                           invT, (int64_t)CIMRGP_NB, (int)CIMRGP_NB, kmat, ld, (const T*)ws, (const T*)nullptr, (int64_t)0, 2, (int)nfull,
+                           blk, CIMRGP_NB * ld + CIMRGP_NB, (int64_t)(CIMRGP_NB / SB) * (SB * SB), (int64_t)0,
+                           bt.sws, bt.sk, bt.sws);
+        CIMRGP_LAUNCH_CHECK(fn);
+    }
+    if (npan > nfull) {
+        hipLaunchKernelGGL((k_invT_panel<T>), dim3(CIMRGP_NB / TR, (unsigned)(npan - nfull), nbatch), dim3(256), 0, st,
+                           invT, kmat, ld, (int)n, (const T*)ws, bt.sk, bt.sws, (int)nfull);
+        CIMRGP_LAUNCH_CHECK(fn);
+    }
     // Round 4: the backward solve takes TWO panels per step through the 512 x 512 inverse
     //     [A 0; B C]^-T = [A^-T  X; 0  C^-T],   X = -A^-T B^T C^-T  (256 x 256, dense),
     // halving its chain of dependent launches (62 -> 32 at n = 8192: 0.33 -> 0.2 ms).  X is what the carried rows' panel
@@ -2432,7 +2448,6 @@ static int build_invT(const T* kmat, int64_t n, int64_t ld, T* ws, hipStream_t s
     const int64_t npairs = (n / CIMRGP_NB) / 2;
     if (npairs > 0) {
         T* xbase = invT + npan * (CIMRGP_NB * CIMRGP_NB);
-        const int64_t blk = (int64_t)CIMRGP_NB * CIMRGP_NB;
         hipLaunchKernelGGL((k_rows_step<T, true>), dim3(CIMRGP_NB / RowsStep<T>::R, (unsigned)(npairs * bt.count)), dim3(256), 0, st,
                            xbase, (int64_t)CIMRGP_NB, (int)CIMRGP_NB, (const T*)(kmat + (int64_t)CIMRGP_NB * ld), ld,
                            (const T*)(ws + (CIMRGP_NB / SB) * (SB * SB)), (const T*)invT, (int64_t)CIMRGP_NB, 1, (int)npairs,
