@@ -132,6 +132,9 @@ struct Knobs {
 const Knobs& knobs();
 // Queues for the carried rows of cimrgp_potrf_rows (1 or 2): cimrgp_set_rows_queues in include/cimrgp.h.
 int rows_queues();
+// Pairs of full panels the backward solve takes in one step (build_invT builds their off-diagonal inverse blocks,
+// potrs_run uses them): a rule of n alone, so that the factorisation and the solve agree without any state.
+static inline int64_t bwd_pairs(int64_t n) { return (n > 5120) ? (n / CIMRGP_NB) / 2 : 0; }
 // (potrf.hip) the look-ahead context's queue that is idle between two factorisations on st: cimrgp_solve_queue
 hipStream_t solve_queue_for(hipStream_t st);
 

@@ -1919,15 +1919,18 @@ static int panel_chain(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, int
 // fused in (`with_prev`: the caller left it out of its updates) or as the solve alone.
 template <typename T>
 static int rows_step_launch(T* b, int64_t ldb, int64_t m, const T* lmat, int64_t ld, const T* ws, int64_t r0, bool with_prev,
-                            hipStream_t st, const char* fn)
+                            hipStream_t st, const char* fn, PotrfBatch bt = PotrfBatch())
 {
-    const dim3 grid((unsigned)((m + RowsStep<T>::R - 1) / RowsStep<T>::R));
+    // (a batch: blockIdx.y = matrix, strides of the rows' arena, the matrices and the workspaces)
+    const dim3 grid((unsigned)((m + RowsStep<T>::R - 1) / RowsStep<T>::R), (unsigned)bt.count);
     if (with_prev)
         hipLaunchKernelGGL((k_rows_step<T, true>), grid, dim3(256), 0, st, b + r0, ldb, (int)m,
-                           (const T*)(lmat + r0 * ld + (r0 - CIMRGP_NB)), ld, (const T*)(ws + (r0 / SB) * (SB * SB)));
+                           (const T*)(lmat + r0 * ld + (r0 - CIMRGP_NB)), ld, (const T*)(ws + (r0 / SB) * (SB * SB)),
+                           (const T*)nullptr, (int64_t)0, 0, 1, (int64_t)0, (int64_t)0, (int64_t)0, (int64_t)0, bt.sb, bt.sk, bt.sws);
     else
         hipLaunchKernelGGL((k_rows_step<T, false>), grid, dim3(256), 0, st, b + r0, ldb, (int)m,
-                           (const T*)(lmat + r0 * ld + r0), ld, (const T*)(ws + (r0 / SB) * (SB * SB)));
+                           (const T*)(lmat + r0 * ld + r0), ld, (const T*)(ws + (r0 / SB) * (SB * SB)),
+                           (const T*)nullptr, (int64_t)0, 0, 1, (int64_t)0, (int64_t)0, (int64_t)0, (int64_t)0, bt.sb, bt.sk, bt.sws);
     CIMRGP_LAUNCH_CHECK(fn);
     return 0;
 }
@@ -1940,11 +1943,11 @@ static int rows_panel_step(T* b, int64_t ldb, int64_t m, const T* lmat, int64_t 
     const int64_t rw = (n - r0 < CIMRGP_NB) ? (n - r0) : CIMRGP_NB;
     const int64_t r1 = r0 + rw;
     GemmBatch gb; gb.count = bt.count; gb.sc = gb.sa = bt.sb; gb.sb = bt.sk;
-    const bool step_ok = knobs().rows_step != 0 && bt.count == 1 && m > 0;
+    const bool step_ok = knobs().rows_step != 0 && m > 0;
     const bool near_pending = grp.near_pending;
     grp.near_pending = false;
     if (step_ok && rw == CIMRGP_NB) {
-        int rcs = rows_step_launch<T>(b, ldb, m, lmat, ld, ws, r0, near_pending, st, fn);
+        int rcs = rows_step_launch<T>(b, ldb, m, lmat, ld, ws, r0, near_pending, st, fn, bt);
         if (rcs) return rcs;
     } else {
         if (near_pending) {                      // (cannot happen: the promise below is made for full panels only)
@@ -2426,7 +2429,9 @@ static int build_invT(const T* kmat, int64_t n, int64_t ld, T* ws, hipStream_t s
     // k_rows_step for all of them (16 workgroups per panel, ~12 us) instead of k_invT_panel's four dependent sub-steps
     // per 32-row strip with their global round trips (40 us at the end of every factorisation); a ragged last panel
     // keeps k_invT_panel.
-    const int64_t nfull = n / CIMRGP_NB;
+    // (single matrices only: in a batch of many small blocks the 16-row workgroups' traffic on the diagonal blocks costs
+    // more than the strips' latency -- 128 blocks of 2048: fit 11.6 -> 12.2 ms)
+    const int64_t nfull = (bt.count == 1) ? n / CIMRGP_NB : 0;
     const int64_t blk = (int64_t)CIMRGP_NB * CIMRGP_NB;
     if (nfull > 0) {
         hipLaunchKernelGGL((k_rows_step<T, false>), dim3(CIMRGP_NB / RowsStep<T>::R, (unsigned)(nfull * bt.count)), dim3(256), 0, st,
@@ -2445,7 +2450,9 @@ static int build_invT(const T* kmat, int64_t n, int64_t ld, T* ws, hipStream_t s
     // halving its chain of dependent launches (62 -> 32 at n = 8192: 0.33 -> 0.2 ms).  X is what the carried rows' panel
     // step computes for the rows of A^-T (already there: invT of the pair's first panel) with a zero right-hand side:
     // one launch of k_rows_step for all pairs of full panels, behind the inverses (potrs_run: bwd_pairs).
-    const int64_t npairs = (n / CIMRGP_NB) / 2;
+    // Above the one-queue size only (bwd_pairs(n) in common.hpp: the solve applies the same rule): below it the launch that
+    // builds X costs what the shorter chain saves.
+    const int64_t npairs = bwd_pairs(n);
     if (npairs > 0) {
         T* xbase = invT + npan * (CIMRGP_NB * CIMRGP_NB);
         hipLaunchKernelGGL((k_rows_step<T, true>), dim3(CIMRGP_NB / RowsStep<T>::R, (unsigned)(npairs * bt.count)), dim3(256), 0, st,

@@ -399,7 +399,7 @@ int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* 
         if (e != hipSuccess) return check_hip(e, fn, "hipMemcpyAsync");
     }   // backward_only: `work` already holds z (RHS-major), put there by the first transpose
     const int64_t last = ((n - 1) / PW) * PW;
-    const int64_t npairs = (n / PW) / 2;                           // pairs of full panels: two per step (k_bwd_alpha2)
+    const int64_t npairs = bwd_pairs(n);                           // pairs of full panels: two per step (k_bwd_alpha2)
     const T* xoff = invT + ((n + PW - 1) / PW) * (PW * PW);
     for (int64_t k0 = last; k0 >= 2 * npairs * PW; k0 -= PW) {    // what lies behind the pairs: at most two panels, singly
         const int w = (int)((n - k0 < PW) ? (n - k0) : PW);
