@@ -122,6 +122,12 @@ namespace {
 // Gram matrix right of the first panel and the carried rows written BESIDE the first panel's chain -- the chain's
 // first diagonal block then took 59-64 us instead of 16-20 under the write traffic and the step got no shorter:
 // HISTORY.md.)
+// The last staged call with a separate solve stage, per device: its streams, its buffers and an event (created once)
+// recorded behind its solve stage.
+struct LastSolve_ { hipStream_t st = nullptr, solve = nullptr; hipEvent_t event = nullptr; const void* k = nullptr; const void* w = nullptr; };
+static std::mutex& last_mutex_() { static std::mutex m; return m; }
+static LastSolve_* last_of_() { static LastSolve_ a[16]; return a; }
+
 template <typename T>
 int block_posterior_typed(const void* x, int64_t n, int d, const void* y, int q, const void* xs, int64_t ns, double ell, double sf2,
                           double noise, void* k, int64_t ldk, void* ws, int32_t* info, void* w, int64_t ldw, void* alpha, void* z,
@@ -155,8 +161,17 @@ int block_posterior_typed(const void* x, int64_t n, int d, const void* y, int q,
         hipError_t e2 = (e1 == hipSuccess) ? hipStreamWaitEvent(to, e, 0) : e1;
         return check_hip(e2, fn, "hipEventRecord / hipStreamWaitEvent");
     };
+    // A caller that passes the buffers of the PREVIOUS call again (one buffer set where two are needed) gets correct
+    // results and no overlap: the front end then waits for that call's solve stage, which still reads them.
+    int rc = 0;
+    if (s_solve != st) {
+        std::lock_guard<std::mutex> guard(last_mutex_());
+        LastSolve_& lp = last_of_()[dev_id];
+        if (lp.event != nullptr && (lp.k == k || lp.w == w))
+            rc = check_hip(hipStreamWaitEvent(s_front, lp.event, 0), fn, "hipStreamWaitEvent");
+    }
     // front end: the Gram matrix, the cross-Gram matrix and the targets as carried rows
-    int rc = rbf_gram_run<T>((const T*)x, n, (const T*)x, n, d, ell, sf2, noise, (T*)k, ldk, true, true, s_front);
+    if (!rc) rc = rbf_gram_run<T>((const T*)x, n, (const T*)x, n, d, ell, sf2, noise, (T*)k, ldk, true, true, s_front);
     if (!rc && ns > 0) rc = rbf_gram_run<T>((const T*)xs, ns, (const T*)x, n, d, ell, sf2, 0.0, wt, ldw, false, false, s_front);
     if (!rc) rc = rhs_rows_run<T>((const T*)y, n, q, wt + ns * ldw, ldw, s_front);
     if (!rc) rc = hand_over(s_front, st);
@@ -166,12 +181,9 @@ int block_posterior_typed(const void* x, int64_t n, int d, const void* y, int q,
     // stage of the PREVIOUS call on the same pair of streams (finished long ago: it ran beside this factorisation), so
     // whatever the caller enqueues on `st` next -- the front end of the call after this one, on the set that solve
     // stage read -- comes after it.
-    static std::mutex last_mutex;
-    struct LastSolve { hipStream_t st = nullptr, solve = nullptr; hipEvent_t event = nullptr; };   // event: created once per device
-    static LastSolve last_of[16];
-    LastSolve& last = last_of[dev_id];
+    LastSolve_& last = last_of_()[dev_id];
     if (!rc && s_solve != st) {
-        std::lock_guard<std::mutex> guard(last_mutex);
+        std::lock_guard<std::mutex> guard(last_mutex_());
         if (last.event != nullptr && last.st == st && last.solve == s_solve)
             rc = check_hip(hipStreamWaitEvent(st, last.event, 0), fn, "hipStreamWaitEvent");
     }
@@ -181,12 +193,14 @@ int block_posterior_typed(const void* x, int64_t n, int d, const void* y, int q,
     if (!rc && ns > 0) rc = predict_from_w_run<T>((const T*)w, ns, n, ldw, (const T*)z, q, sf2, add_noise ? noise : 0.0, nullptr, nullptr,
                                                    (T*)mean, (T*)var, accumulate, s_solve, 1, nullptr, 0);
     if (!rc && s_solve != st) {
-        std::lock_guard<std::mutex> guard(last_mutex);
+        std::lock_guard<std::mutex> guard(last_mutex_());
         if (last.event == nullptr && hipEventCreateWithFlags(&last.event, hipEventDisableTiming) != hipSuccess) last.event = nullptr;
         if (last.event != nullptr) {
             rc = check_hip(hipEventRecord(last.event, s_solve), fn, "hipEventRecord");
             last.st = st;
             last.solve = s_solve;
+            last.k = k;
+            last.w = w;
         }
     }
     return rc;

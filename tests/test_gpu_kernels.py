@@ -468,11 +468,13 @@ def test_potrf_rows_batched_matches_single(dev, dt, tol, n, batch, m):
         assert got[1] > 0 and all(g == 0 for j, g in enumerate(got) if j != 1)
 
 
+@pytest.mark.parametrize("nsets", [2, 1])
 @pytest.mark.parametrize("n,ns,q", [(700, 50, 2), (5632, 130, 2)])
-def test_block_posterior_solve_stage_on_the_idle_context_queue(dev, n, ns, q):
+def test_block_posterior_solve_stage_on_the_idle_context_queue(dev, n, ns, q, nsets):
     """cimrgp_solve_queue: the solve stage of block i on the look-ahead context's idle queue, beside the front end and
     first panels of block i+1, over TWO rotating buffer sets with no ordering by the caller other than its own reads:
-    bit for bit the one-stream results (small n: the factorisation itself does not use the context)."""
+    bit for bit the one-stream results (small n: the factorisation itself does not use the context).  With ONE buffer set
+    (a caller's mistake) the front end waits for the previous solve stage: still the right results, no overlap."""
     tdt = torch.float64
     nblocks = 5
     rng = np.random.default_rng(n + 1)
@@ -499,9 +501,9 @@ def test_block_posterior_solve_stage_on_the_idle_context_queue(dev, n, ns, q):
     cur = torch.cuda.current_stream()
     sq = dev.solve_queue(cur)
     assert sq.cuda_stream != cur.cuda_stream
-    sets = [buffers(), buffers()]
+    sets = [buffers() for _ in range(nsets)]
     for i, (xd, yd, xsd) in enumerate(blocks):
-        b = sets[i % 2]
+        b = sets[i % nsets]
         dev.block_posterior(xd, yd, xsd, ell, sf2, noise, b["kbuf"], b["wbuf"], b["ws"], b["info"], b["alpha"], b["z"],
                             means[nblocks + i], vars_[nblocks + i], scratch=b["scratch"], streams=(cur, cur, sq))
     torch.cuda.synchronize()
