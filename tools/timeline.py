@@ -37,8 +37,24 @@ def main():
     for i, r in enumerate(rows):
         if "k_rbf_gram" in r["name"]:
             start = i
-    rows = rows[start:]
-    t0 = rows[0]["s"]
+    if len(sys.argv) > 2 and sys.argv[2] == "boundary":
+        # a window around the LAST Gram build (pipelined steps: the previous step's tail and solve stage beside the
+        # next step's front end and first panels): 400 us before it to 900 us after it
+        # (argv[3] = K: around the K-th symmetric Gram build instead -- the timed steps of bench.py come before its
+        # stage and potrf-alone sections, which build Gram matrices too)
+        if len(sys.argv) > 3:
+            grams = [r for r in rows if "k_rbf_gram" in r["name"]]
+            big = max(r["wg"] for r in grams)
+            sym = [r for r in grams if r["wg"] == big]
+            tg = sym[int(sys.argv[3]) - 1]["s"]
+        else:
+            tg = rows[start]["s"]
+        rows = [r for r in rows if tg - 400_000 <= r["s"] <= tg + 900_000]
+        t0 = tg
+        print("# window around the last Gram build (time 0): the previous step's tail and solve stage | the next step's front end and first panels")
+    else:
+        rows = rows[start:]
+        t0 = rows[0]["s"]
     queues = {}
     print("# columns: start_us end_us duration_us queue kernel workgroups")
     print("# total span: %.1f us" % ((max(r["e"] for r in rows) - t0) / 1e3))
