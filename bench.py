@@ -288,7 +288,11 @@ def main():
                     help="1: consecutive (independent) blocks pipelined over three streams and three buffer sets "
                          "(cimrgp_block_posterior_staged); 0: one stream, one set; default: 1 unless ranks share one GPU")
     ap.add_argument("--nccl-world1", action="store_true",
-                    help="one rank, backend nccl initialised, the step's reduce goes through RCCL unconditionally")
+                    help="one rank, an RCCL communicator of one created, the step's reduce goes through RCCL unconditionally")
+    ap.add_argument("--comm", default="cabi", choices=["cabi", "torch"],
+                    help="the step's collective: cabi = cimrgp_allreduce_sum (the C ABI's RCCL communicator) enqueued on the step's "
+                         "solve queue -- no stream of its own; torch = torch.distributed's all_reduce (backend nccl: ProcessGroupNCCL "
+                         "brings a stream of its own, a fifth queue for a runtime that serves four: round-4 record)")
     ap.add_argument("--rows-queues", type=int, default=0, choices=[0, 1, 2],
                     help="queues for the carried rows (cimrgp_set_rows_queues); 0 = the default policy")
     args = ap.parse_args()
@@ -309,12 +313,24 @@ def main():
     # CIMRGP_BENCH_REHEARSAL=gloo: rehearse the N > 1 path on a box with ONE GPU (all ranks on
     # cuda:0, gloo carrying the device tensors); the driver's multi-GPU runs use nccl = RCCL
     rehearsal = os.environ.get("CIMRGP_BENCH_REHEARSAL", "")
+    # The DATA path's collective is RCCL in every non-rehearsal run.  --comm cabi (default): the C ABI's communicator
+    # (cimrgp_comm_* / cimrgp_allreduce_sum, RCCL loaded by the library) enqueued on the step's own solve queue; the
+    # process group is then only the control plane (the id's broadcast, the barriers around the timed region, the MAX
+    # over ranks of the time) and runs on gloo, so that no RCCL stream of torch's exists in the process.
+    # --comm torch: backend nccl, the step's all_reduce through torch.distributed (the round-4 form).
+    cabi = (args.comm == "cabi") and not rehearsal and args.config == 2
+    comm = None
     if args.gpus > 1 or world > 1 or args.nccl_world1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(0 if rehearsal else local_rank)
         if rehearsal:
             td.init_process_group(rehearsal, rank=rank, world_size=world)
+        elif cabi:
+            td.init_process_group("gloo", rank=rank, world_size=world)
+            ident = [_lib.Comm.unique_id() if rank == 0 else None]
+            td.broadcast_object_list(ident, src=0)
+            comm = _lib.Comm(world, rank, ident[0])           # collective; binds the current device (set above)
         else:
             # device_id: the communicator is bound to this rank's GPU up front (no guessing in barrier())
             td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -384,6 +400,14 @@ def main():
     step_no = [0]
     last_set = [0]
 
+    def reduce_begin(fused, stream):
+        """Start the step's one collective behind the work already enqueued on ``stream``.  C ABI: enqueued ON that stream
+        (ordered by it: no handle); torch.distributed: its own stream, a handle whose wait() makes the current stream wait."""
+        if comm is not None:
+            comm.allreduce_sum((_lib.F64 if args.dtype == "f64" else _lib.F32), fused.data_ptr(), fused.numel(), stream.cuda_stream)
+            return None
+        return dist.allreduce_sum_begin(fused, force=args.nccl_world1)
+
     def step(wait_inside=False):
         si = step_no[0] % nsets
         step_no[0] += 1
@@ -399,7 +423,7 @@ def main():
                 t.zero_()
             dev.block_posterior(xd, yd, xsd, ell, sf2, noise, b["kbuf"], b["wbuf"], b["ws"], b["info"], b["alpha"], b["zbuf"],
                                 b["mean"], b["var"], scratch=b["scratch"])
-            pending[si] = dist.allreduce_sum_begin(b["fused"], force=args.nccl_world1)    # the one collective
+            pending[si] = reduce_begin(b["fused"], torch.cuda.current_stream())           # the one collective
             if wait_inside and pending[si] is not None:
                 pending[si].wait()
                 pending[si] = None
@@ -418,12 +442,14 @@ def main():
         dev.block_posterior(xd, yd, xsd, ell, sf2, noise, b["kbuf"], b["wbuf"], b["ws"], b["info"], b["alpha"], b["zbuf"],
                             b["mean"], b["var"], scratch=b["scratch"], streams=streams)
         with torch.cuda.stream(s_solve):
-            pending[si] = dist.allreduce_sum_begin(b["fused"], force=args.nccl_world1)    # the one collective
+            pending[si] = reduce_begin(b["fused"], s_solve)                               # the one collective
             if wait_inside and pending[si] is not None:
                 pending[si].wait()
                 pending[si] = None
             done[si] = torch.cuda.Event()
             done[si].record(s_solve)
+        if wait_inside and comm is not None:
+            s_front.wait_event(done[si])         # C-ABI collective: stream-ordered, so "waiting inside" = nothing of the next step beside it
 
     # the same work as five separate calls (the boundary's fine-grained entry points), with an event between the
     # stages: run AFTER the timed region, for `stage_ms` only (tests/ hold the two forms to bit-equality)
@@ -523,7 +549,7 @@ def main():
     _lib.check(lib.cimrgp_profile_collect_bytes(ctypes.byref(al_ms), ctypes.byref(al_fl), ctypes.byref(al_by), ctypes.byref(al_cnt)),
                "cimrgp_profile_collect_bytes")
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if cabi else device)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         dt = float(t.item())
     assert int(info.item()) == 0
@@ -549,7 +575,8 @@ def main():
                                    "per GPU, q=2 outputs, N/4=%d test points, ell=0.1, sf2=1, noise=0.01" % (n, ns),
                        "partitions_per_gpu": 1,
                        "parallelism": "independent partitions, 1 all-reduce/step (started at the end of a step, waited for by the stream at the start of the next)",
-                       "backend": (rehearsal or "nccl") if td.is_initialized() else "none",
+                       "backend": ((rehearsal or ("rccl through the C ABI (cimrgp_allreduce_sum on the step's solve queue); control plane gloo"
+                                                   if comm is not None else "nccl")) if td.is_initialized() else "none"),
                        "rows_queues": int(lib.cimrgp_get_rows_queues())},
             "reduce_selfcheck_max_abs_diff": reduce_diff,
             "cholesky_gflops": chol_gflops,
@@ -562,7 +589,8 @@ def main():
             "pipelined_steps": bool(pipeline),
             "reduce_overlapped": bool(world > 1 or args.nccl_world1),
             "drained_step_ms": drained_ms,
-            "stage_ms": {"measured": "the same work as five separate calls, after the timed region (median of 3)",
+            "stage_ms": {"measured": "the same work as five separate calls on ONE stream, after the timed region (median of 3): a different "
+                                     "schedule from the timed, pipelined step -- its stages do not add up to ms_per_step",
                          "gram": float(stage_ms[0]), "cross_gram_and_rhs_rows": float(stage_ms[1]),
                          "potrf_with_carried_rows": float(stage_ms[2]), "backward_solve_and_predict": float(stage_ms[3]),
                          "potrf_alone": chol_ms},
@@ -595,22 +623,10 @@ def main():
             fp = {"file": "profiles/" + PMC_PROFILE, "commit": pj.get("commit"), "sources_sha256": pj.get("sources_sha256"),
                   "matches_this_code": fresh,
                   "traffic_bytes_per_launch": pj.get("trailing_update", {}).get("traffic_bytes_per_launch"),
-                  "sustained_clock_ghz": pj.get("sustained_clock", {}).get("clock_ghz"),
                   "gram_hbm_write_gbps_rocprof": pj.get("gram", {}).get("hbm_write_GBps_rocprof"),
                   "gram_frac_of_hbm_peak": pj.get("gram", {}).get("frac_of_8TBps")}
             out["from_profile"] = fp
             if fresh:
-                clk = fp["sustained_clock_ghz"]
-                if clk:
-                    # the spec peak is quoted at 2.4 GHz; the part sustains less under FP64 matrix load (GRBM cycles of the
-                    # kernel over its traced duration): what the kernel reaches of the peak AT THE CLOCK IT IS GIVEN
-                    out["roofline"]["sustained_clock_ghz"] = clk
-                    out["roofline"]["peak_at_sustained_clock"] = peak * clk / 2.4
-                    out["roofline"]["frac_of_sustained_peak"] = achieved / (peak * clk / 2.4)
-                    out["roofline"]["sustained_clock_note"] = ("GRBM_GUI_ACTIVE / 8 / traced duration under-reads (XCDs that finish early stop "
-                                                               "counting): a register-only v_mfma_f64 loop sustains 0.99 of the nominal "
-                                                               "peak on this part (tools/lab/mfma_loop.hip, HISTORY.md round 4) -- `frac` "
-                                                               "against the nominal peak is the figure to judge")
                 out["roofline"]["traffic"] = fp["traffic_bytes_per_launch"]
                 out["roofline"]["traffic_unit"] = ("bytes/launch (PMC upper bound: 2*FETCH_SIZE + WRITE_SIZE, separate passes; "
                                                    "%s, commit %s)" % (fp["file"], fp["commit"]))
@@ -625,6 +641,8 @@ def main():
         if out.get("parity_ok") is False:
             raise SystemExit("bench.py: the GPU posterior differs from the oracle by more than 1e-5: mean %.3e var %.3e"
                              % (out["parity_rel_err_mean"], out["parity_rel_err_var"]))
+    if comm is not None:
+        comm.close()
     if td.is_initialized():
         td.destroy_process_group()
 

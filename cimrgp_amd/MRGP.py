@@ -207,18 +207,30 @@ class MultiResolutionGaussianProcess(object):
         # Layers from self._first_local on are LOCAL (dist.plan_layers): a rank's blocks lie inside row ranges whose
         # coarser predictions it computed itself, so the residual chain needs no exchange there; their predictions
         # (and failure flags) are assembled on every rank by ONE all-reduce after the sweep.
+        # NOT when a layer takes statistics over ALL its regions (shared bias / shared noise: bias_region_specific or
+        # noise_region_specific False): those read the whole latent function, which a rank holds on its own ranges
+        # only while the layers are local -- then every layer is exchanged as it is fitted (round 5).
         local_from = self._first_local if self.world_size > 1 else self.n_layers
+        if any(p.needs_whole_layer() for p in self.posterior_obj[local_from:]):
+            local_from = self.n_layers
+        self._local_from = local_from
         n_local = max(0, self.n_layers - local_from) if self.world_size > 1 else 0
-        tail = torch.zeros(n_local * (n * q + 1), dtype=self.dtype, device=self.device) if n_local else None
+        # every local layer writes a zero-offset (N x q) array of its own (the batched fit addresses a block by ONE row
+        # offset from the start of the storage: a view into a shared buffer at an odd offset would disable it);
+        # the flags sit in a small tensor; both are copied into ONE flat buffer for the single collective
+        local_pred = [torch.zeros((n, q), dtype=self.dtype, device=self.device) for _ in range(n_local)]
+        local_flag = torch.zeros(max(n_local, 1), dtype=self.dtype, device=self.device)
         for j in range(self.n_layers):
             self._layer_events[j].record()
             self._f_bar_layers[j] = f_bar
-            # [layer's training-point prediction (N x q) | failure flag]: ONE buffer, one collective
-            if j >= local_from and n_local:
-                buf = tail[(j - local_from) * (n * q + 1):(j - local_from + 1) * (n * q + 1)]
+            is_local = j >= local_from and n_local > 0
+            if is_local:
+                layer_pred, flag = local_pred[j - local_from], local_flag[j - local_from:j - local_from + 1]
+                buf = None
             else:
+                # [layer's training-point prediction (N x q) | failure flag]: ONE buffer, one collective
                 buf = torch.zeros(n * q + 1, dtype=self.dtype, device=self.device)
-            layer_pred = buf[:n * q].view(n, q)
+                layer_pred, flag = buf[:n * q].view(n, q), buf[n * q:]
             owned = self._owned(j)
             self.posterior_obj[j].update_scale_given_axis(
                 y_mean=self._slices(self._y, j), x=self.x[j], f_bar=self._slices(f_bar, j),
@@ -226,21 +238,22 @@ class MultiResolutionGaussianProcess(object):
             # A non-PD block must fail on EVERY rank, not only on its owner (whose exception
             # would leave the others blocked in the collective): the blocks' LAPACK-style info
             # words ride in the same all-reduce and every rank raises after it.
-            self.posterior_obj[j].failure_flag(owned, out=buf[n * q:])
-            if not (j >= local_from and n_local):
+            self.posterior_obj[j].failure_flag(owned, out=flag)
+            if not is_local:
                 # residual chain (Stats.py:126-157): every rank needs the whole layer's prediction
                 dist.allreduce_sum_(buf, self.group)
                 failed[j:j + 1].copy_(buf[n * q:])           # read ONCE, after the sweep: the fit stays enqueue-only
             f_bar = f_bar + layer_pred                       # local layers: valid on this rank's own ranges, all it reads
         if n_local:
+            tail = torch.cat([t.reshape(-1) for t in local_pred] + [local_flag[:n_local]])
             dist.allreduce_sum_(tail, self.group)
             # the latent function of every layer, now complete on every rank
             f_bar = self._f_bar_layers[local_from]
             for j in range(local_from, self.n_layers):
-                part = tail[(j - local_from) * (n * q + 1):(j - local_from + 1) * (n * q + 1)]
+                k = j - local_from
                 self._f_bar_layers[j] = f_bar
-                f_bar = f_bar + part[:n * q].view(n, q)
-                failed[j:j + 1].copy_(part[n * q:])
+                f_bar = f_bar + tail[k * n * q:(k + 1) * n * q].view(n, q)
+            failed[local_from:].copy_(tail[n_local * n * q:])
         self._layer_events[self.n_layers].record()
         # (a host read per layer made the device wait for the host's enqueue of the next layer: 2-3 ms on the
         # fine layers of config 4.  After a failed factorisation the later layers run on garbage -- harmless:

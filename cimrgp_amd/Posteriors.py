@@ -206,13 +206,18 @@ class DensePosterior(object):
         self.blocks = [None] * self.n_regions
         self.batches = []                # _FittedBatch records of the last sweep (equal-sized blocks fitted together)
 
+    def needs_whole_layer(self):
+        """Whether the layer's fit reads statistics over ALL its regions (a shared bias, or a shared noise taken from
+        the targets): such a layer needs the whole latent function on every rank (MRGP._fit)."""
+        return not (self.bias_region_specific and (self.noise_region_specific or self.kernel.noise is not None))
+
     def update_scale_given_axis(self, y_mean, x, f_bar, train_out, owned=None, keep_factors=True):
         """``y_mean``, ``x``, ``f_bar``, ``train_out``: lists indexed by region of device
         views (the reference passes lists indexed by region too, Posteriors.py:35).
         ``owned``: iterable of the region ids this process computes (default all)."""
         regions = range(self.n_regions) if owned is None else owned
         shared_bias = shared_noise = None
-        if not (self.bias_region_specific and (self.noise_region_specific or self.kernel.noise is not None)):
+        if self.needs_whole_layer():
             # layer-wide statistics over the concatenation of all regions (regions are
             # contiguous slices of one array: region 0's base with the total length)
             y_all, f_all = self._whole_layer(y_mean), self._whole_layer(f_bar)

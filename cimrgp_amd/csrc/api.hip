@@ -122,11 +122,46 @@ namespace {
 // Gram matrix right of the first panel and the carried rows written BESIDE the first panel's chain -- the chain's
 // first diagonal block then took 59-64 us instead of 16-20 under the write traffic and the step got no shorter:
 // HISTORY.md.)
-// The last staged call with a separate solve stage, per device: its streams, its buffers and an event (created once)
-// recorded behind its solve stage.
-struct LastSolve_ { hipStream_t st = nullptr, solve = nullptr; hipEvent_t event = nullptr; const void* k = nullptr; const void* w = nullptr; };
-static std::mutex& last_mutex_() { static std::mutex m; return m; }
-static LastSolve_* last_of_() { static LastSolve_ a[16]; return a; }
+// Staged calls in flight, per device (round 5: one record per (stream, stream_solve) PAIR -- round 4 kept one record
+// per device, so two caller stream pairs on one device overwrote each other's and lost both safety nets below).
+// A record = the latest staged call of its pair: an event (created once per slot) recorded behind its solve stage and
+// the call's whole buffer set (k, w, workspace, alpha, z, scratch: the solve stage reads or writes every one of them).
+struct StagedRec_ {
+    hipStream_t st = nullptr, solve = nullptr;
+    hipEvent_t event = nullptr;
+    bool live = false;
+    unsigned long long age = 0;
+    const void* buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+constexpr int STAGED_DEVS = 16, STAGED_RECS = 32, STAGED_RING = 64;
+struct StagedDev_ {
+    std::mutex m;
+    StagedRec_ rec[STAGED_RECS];
+    unsigned long long clock = 0;
+    hipEvent_t ring[STAGED_RING] = {};          // hand-over events between a call's stages
+    unsigned ring_next = 0;
+};
+static StagedDev_* staged_devs_() { static StagedDev_ a[STAGED_DEVS]; return a; }
+
+// cimrgp_shutdown: the events above (idle devices only: the caller has synchronised)
+static int staged_shutdown_()
+{
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    for (int d = 0; d < STAGED_DEVS; ++d) {
+        StagedDev_& sd = staged_devs_()[d];
+        std::lock_guard<std::mutex> guard(sd.m);
+        bool any = false;
+        for (auto& r : sd.rec) any = any || r.event != nullptr;
+        for (auto& e : sd.ring) any = any || e != nullptr;
+        if (!any) continue;
+        (void)hipSetDevice(d);
+        for (auto& r : sd.rec) { if (r.event) (void)hipEventDestroy(r.event); r = StagedRec_(); }
+        for (auto& e : sd.ring) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    }
+    if (have_cur) (void)hipSetDevice(cur);
+    return 0;
+}
 
 template <typename T>
 int block_posterior_typed(const void* x, int64_t n, int d, const void* y, int q, const void* xs, int64_t ns, double ell, double sf2,
@@ -138,19 +173,17 @@ int block_posterior_typed(const void* x, int64_t n, int d, const void* y, int q,
     const char* fn = "cimrgp_block_posterior";
     T* wt = (T*)w;
     int dev_id = 0;                                   // the events below belong to the device they were created on
-    if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 16) dev_id = 0;
+    if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= STAGED_DEVS) dev_id = 0;
+    StagedDev_& sd = staged_devs_()[dev_id];
     // `to` continues where `from` stands now (an event that lives until both have passed it)
     auto hand_over = [&](hipStream_t from, hipStream_t to) -> int {
         if (from == to) return 0;
         // a ring of events per device, created once (a wait captures the record that precedes it: an event may be
         // recorded again while an earlier wait on it is still queued)
-        static std::mutex ring_mutex;
-        static hipEvent_t ring[16][64] = {};
-        static unsigned ring_next = 0;
         hipEvent_t e = nullptr;
         {
-            std::lock_guard<std::mutex> guard(ring_mutex);
-            hipEvent_t& slot = ring[dev_id][ring_next++ % 64];
+            std::lock_guard<std::mutex> guard(sd.m);
+            hipEvent_t& slot = sd.ring[sd.ring_next++ % STAGED_RING];
             if (slot == nullptr) {
                 hipError_t e0 = hipEventCreateWithFlags(&slot, hipEventDisableTiming);
                 if (e0 != hipSuccess) { slot = nullptr; return check_hip(e0, fn, "hipEventCreate"); }
@@ -161,14 +194,19 @@ int block_posterior_typed(const void* x, int64_t n, int d, const void* y, int q,
         hipError_t e2 = (e1 == hipSuccess) ? hipStreamWaitEvent(to, e, 0) : e1;
         return check_hip(e2, fn, "hipEventRecord / hipStreamWaitEvent");
     };
-    // A caller that passes the buffers of the PREVIOUS call again (one buffer set where two are needed) gets correct
-    // results and no overlap: the front end then waits for that call's solve stage, which still reads them.
+    const void* mine[6] = {k, w, ws, alpha, z, scratch};
+    // Safety net 1: ANY buffer of a staged call whose solve stage may still be running (any pair of streams of this
+    // device, a plain call on the same set included) handed in again -- one buffer set where two are needed: the
+    // front end waits for that solve stage; correct results, no overlap.
     int rc = 0;
-    if (s_solve != st) {
-        std::lock_guard<std::mutex> guard(last_mutex_());
-        LastSolve_& lp = last_of_()[dev_id];
-        if (lp.event != nullptr && (lp.k == k || lp.w == w))
-            rc = check_hip(hipStreamWaitEvent(s_front, lp.event, 0), fn, "hipStreamWaitEvent");
+    {
+        std::lock_guard<std::mutex> guard(sd.m);
+        for (auto& r : sd.rec) {
+            if (!r.live || r.solve == s_front || rc) continue;       // same queue: already ordered
+            bool shares = false;
+            for (const void* a : mine) for (const void* b : r.buf) shares = shares || (a != nullptr && a == b);
+            if (shares) rc = check_hip(hipStreamWaitEvent(s_front, r.event, 0), fn, "hipStreamWaitEvent");
+        }
     }
     // front end: the Gram matrix, the cross-Gram matrix and the targets as carried rows
     if (!rc) rc = rbf_gram_run<T>((const T*)x, n, (const T*)x, n, d, ell, sf2, noise, (T*)k, ldk, true, true, s_front);
@@ -177,15 +215,15 @@ int block_posterior_typed(const void* x, int64_t n, int d, const void* y, int q,
     if (!rc) rc = hand_over(s_front, st);
     if (!rc) rc = potrf_run<T>((T*)k, n, ldk, (T*)ws, info, wt, ns + q, ldw, st);
     if (!rc) rc = hand_over(st, s_solve);
-    // Two buffer sets in rotation need no ordering by the caller: behind its factorisation `st` waits for the solve
-    // stage of the PREVIOUS call on the same pair of streams (finished long ago: it ran beside this factorisation), so
-    // whatever the caller enqueues on `st` next -- the front end of the call after this one, on the set that solve
-    // stage read -- comes after it.
-    LastSolve_& last = last_of_()[dev_id];
+    // Safety net 2: two buffer sets in rotation need no ordering by the caller: behind its factorisation `st` waits for
+    // the solve stage of the PREVIOUS call on the same pair of streams (finished long ago: it ran beside this
+    // factorisation), so whatever the caller enqueues on `st` next -- the front end of the call after this one, on the
+    // set that solve stage read -- comes after it.
     if (!rc && s_solve != st) {
-        std::lock_guard<std::mutex> guard(last_mutex_());
-        if (last.event != nullptr && last.st == st && last.solve == s_solve)
-            rc = check_hip(hipStreamWaitEvent(st, last.event, 0), fn, "hipStreamWaitEvent");
+        std::lock_guard<std::mutex> guard(sd.m);
+        for (auto& r : sd.rec)
+            if (r.live && r.st == st && r.solve == s_solve && !rc)
+                rc = check_hip(hipStreamWaitEvent(st, r.event, 0), fn, "hipStreamWaitEvent");
     }
     // z = L^-1 y (the last q carried rows), alpha = L^-T z, mean = W z, var = sf2 - sum W^2 (+ noise)
     if (!rc) rc = rows_to_z_run<T>(wt + ns * ldw, ldw, n, q, (T*)z, (T*)alpha, s_solve);
@@ -193,15 +231,28 @@ int block_posterior_typed(const void* x, int64_t n, int d, const void* y, int q,
     if (!rc && ns > 0) rc = predict_from_w_run<T>((const T*)w, ns, n, ldw, (const T*)z, q, sf2, add_noise ? noise : 0.0, nullptr, nullptr,
                                                    (T*)mean, (T*)var, accumulate, s_solve, 1, nullptr, 0);
     if (!rc && s_solve != st) {
-        std::lock_guard<std::mutex> guard(last_mutex_());
-        if (last.event == nullptr && hipEventCreateWithFlags(&last.event, hipEventDisableTiming) != hipSuccess) last.event = nullptr;
-        if (last.event != nullptr) {
-            rc = check_hip(hipEventRecord(last.event, s_solve), fn, "hipEventRecord");
-            last.st = st;
-            last.solve = s_solve;
-            last.k = k;
-            last.w = w;
+        // this call becomes its pair's record (its slot, or a free one, or the slot of the pair idle longest -- whose
+        // solve stage is waited for on the host first, so that no net is lost: 32 pairs per device, rare)
+        std::lock_guard<std::mutex> guard(sd.m);
+        StagedRec_* slot = nullptr;
+        for (auto& r : sd.rec) if (r.live && r.st == st && r.solve == s_solve) slot = &r;
+        if (!slot) for (auto& r : sd.rec) if (!r.live && !slot) slot = &r;
+        if (!slot) {
+            slot = &sd.rec[0];
+            for (auto& r : sd.rec) if (r.age < slot->age) slot = &r;
+            (void)hipEventSynchronize(slot->event);
         }
+        if (slot->event == nullptr && hipEventCreateWithFlags(&slot->event, hipEventDisableTiming) != hipSuccess) {
+            slot->event = nullptr;
+            slot->live = false;
+            return check_hip(hipErrorOutOfMemory, fn, "hipEventCreate");
+        }
+        rc = check_hip(hipEventRecord(slot->event, s_solve), fn, "hipEventRecord");
+        slot->st = st;
+        slot->solve = s_solve;
+        slot->live = (rc == 0);
+        slot->age = ++sd.clock;
+        for (int i = 0; i < 6; ++i) slot->buf[i] = mine[i];
     }
     return rc;
 }
@@ -660,7 +711,7 @@ int cimrgp_set_rows_queues(int queues)
 
 int cimrgp_get_rows_queues(void) { return rows_queues(); }
 
-int cimrgp_shutdown(void) { return potrf_shutdown(); }
+int cimrgp_shutdown(void) { const int rc = potrf_shutdown(); staged_shutdown_(); return rc; }
 
 int cimrgp_tuning_build(void)
 {

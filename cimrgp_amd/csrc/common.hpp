@@ -73,6 +73,49 @@ static __device__ __forceinline__ typename Mx<T>::acc_t acc_zero() {
     return z;
 }
 
+// ------------------------------------------------------- LDS-only barriers ----
+// lds_barrier: waits for this wave's LDS traffic, not for global stores in flight (a plain __syncthreads() also
+// drains vmcnt, i.e. every store's round trip).  A real fence pair restricted to the LDS address space around
+// s_barrier, NOT inline assembly (round 4): the instructions are the same (s_waitcnt lgkmcnt(0); s_barrier), but the
+// compiler does not treat an assembly statement's "memory" clobber as an access to __shared__ arrays whose address
+// never leaves the kernel -- it kept a value read from LDS two barriers earlier in registers across such a statement
+// (potrf.hip, the pivot loop) and may move LDS accesses across one.  Fences are what __syncthreads() is made of and
+// do order such accesses.
+static __device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// lds_settle: a wave that has just WRITTEN words other waves will read behind the next barrier reads one of them back
+// first (the last one it wrote, or any LDS word: the LDS executes one wave's accesses in issue order, so the load's
+// data can only return once every earlier store of the wave has been performed).  Round 5: measured on gfx950 with a
+// second workgroup on the compute unit (tools/lab/race_probe.hip, HISTORY.md): the LAST one or two ds_write
+// instructions a wave issued ahead of `s_waitcnt lgkmcnt(0); s_barrier` were not yet in the LDS array when another
+// wave's ds_read, issued right behind the barrier, read their words -- it got, bit for bit, what the words held before
+// (1.7-3 % of panel chains beside an FP32 trailing update; 0 of 1999 with the read-back).  The wait for a STORE's
+// lgkmcnt does not imply visibility to other waves there; the wait for a LOAD's data does.
+template <typename T>
+static __device__ __forceinline__ void lds_settle(const T* written)
+{
+    const volatile T* p = written;
+    const T v = *p;
+    asm volatile("" :: "v"(v));          // the value is "used": the wait for it stays ahead of whatever follows
+}
+
+// lds_barrier_nowait: the barrier WITHOUT the wait for this wave's LDS traffic, for the one place that needs it: a
+// buffer every wave has finished READING (each read's value has been consumed by an instruction ahead of the barrier,
+// so the read itself is complete) is rewritten behind the barrier, while reads of ANOTHER buffer may stay in flight
+// across it.  The compiler-only fences (no instruction) keep the compiler from moving or caching LDS accesses across
+// the barrier; the hardware orders the rest: a wave's LDS write issued behind s_barrier cannot overtake a read
+// another wave completed ahead of it.
+static __device__ __forceinline__ void lds_barrier_nowait()
+{
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    __builtin_amdgcn_s_barrier();
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+}
+
 // Zero the elements of a 16-byte chunk whose k index is >= kvalid.
 template <typename T>
 static __device__ __forceinline__ uint4 mask_chunk(uint4 v, int kfirst, int kvalid);

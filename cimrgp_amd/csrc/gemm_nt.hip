@@ -163,15 +163,17 @@ static __device__ __forceinline__ int pers_tile_number(int w, int i, int grid, i
 #ifndef PERS_EXP
 #define PERS_EXP 0
 #endif
+// Round 5: the two barriers of a stage are fences + s_barrier (common.hpp), no longer inline assembly whose "memory"
+// clobber the compiler does not apply to a __shared__ array whose address never escapes (the operand ring here).
 #if PERS_EXP == 1
-#define PERS_BARRIER_A() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define PERS_BARRIER_A() lds_barrier()
 #define PERS_BARRIER_B() do { } while (0)
 #elif PERS_EXP == 2
-#define PERS_BARRIER_A() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define PERS_BARRIER_A() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
 #define PERS_BARRIER_B() do { } while (0)
 #else
-#define PERS_BARRIER_A() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#define PERS_BARRIER_B() asm volatile("s_barrier" ::: "memory")
+#define PERS_BARRIER_A() lds_barrier()              /* stage kt+1's LDS writes are done: s_waitcnt lgkmcnt(0); s_barrier */
+#define PERS_BARRIER_B() lds_barrier_nowait()       /* every wave has consumed stage kt's fragments: s_barrier alone */
 #endif
 constexpr int PERS_THREADS = 512;
 constexpr int PERS_STAGES = 16;

@@ -344,19 +344,40 @@ static __device__ __forceinline__ void run_rider(unsigned char* smem, const Ride
 // Mi[j,:] r_j, r_j = 1/sqrt(S[j][j]); the row operations that reduce S are
 // applied to Mi.
 // ---------------------------------------------------------------------------
-// LDS-only barrier: waits for this wave's LDS traffic, not for global stores in
-// flight (a plain __syncthreads() also drains vmcnt, i.e. every store's round trip).
-// Round 4: a real fence pair restricted to the LDS address space, not inline assembly.  The instructions are the same
-// (s_waitcnt lgkmcnt(0); s_barrier), but the compiler did not treat the assembly's "memory" clobber as a write to
-// __shared__ arrays whose address never leaves the kernel: with the pivot loop unrolled it kept a tile wave's
-// left operand, read from LDS two barriers earlier at the same address, in registers (the pivot wave had
-// rewritten it in between).  Fences are what __syncthreads() is made of and do order such accesses.
-static __device__ __forceinline__ void lds_barrier()
+// (lds_barrier: common.hpp)
+#ifdef CIMRGP_RACE_DUMP     /* tools/lab/race_probe.hip only: what the pivot wave read and published, what a gathering wave wrote */
+__device__ float* g_race_buf;                 // [launch slot][RD_WORDS]
+__device__ int g_race_slot;
+constexpr int RD_PIV = 16 * 64 * 8;            // pivot wave, per block and lane: its 4 columns as read, as published
+constexpr int RD_GAT = 16 * 64 * 32;           // gathering tile wave, per step and lane: 16 values as they stand one barrier later, 16 read back from LDS
+constexpr int RD_WORDS = RD_PIV + RD_GAT;
+#define RACE_ARG , int dslot
+#define RACE_PASS , dslot
+#else
+#define RACE_ARG
+#define RACE_PASS
+#endif
+
+#ifdef RACE_NOPRIO          /* tools/lab/race_probe.hip only: the chain kernels at the default wave priority */
+#define CHAIN_SETPRIO() do { } while (0)
+#else
+#define CHAIN_SETPRIO() __builtin_amdgcn_s_setprio(3)
+#endif
+#ifdef CIMRGP_RACE_PDUMP    /* tools/lab/race_probe.hip only, the lightest record: what the pivot wave READ as gathered, per block (one 16-byte store per lane) */
+__device__ float* g_race_pbuf;                // [4 sub-blocks of the panel][16 blocks][64 lanes][4]
+#endif
+#ifdef CIMRGP_RACE_DETECT   /* tools/lab/race_probe.hip only: every LDS value a wave takes right behind a barrier is read AGAIN at the end of its step */
+__device__ int g_race_cnt[4];                 // 0: tile wave's left operand (hs), 1: its right operand (cs), 2: pivot wave's gathered columns (pcol)
+__device__ float g_race_rec[3][64][6];        // per kind, first 64 events: block p, lane, index, first value, second value, wave/tile
+static __device__ __forceinline__ void race_note(int kind, int p, int lane, int idx, float first, float second, int who)
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    const int e = atomicAdd(&g_race_cnt[kind], 1);
+    if (e < 64) {
+        float* r = g_race_rec[kind][e];
+        r[0] = (float)p; r[1] = (float)lane; r[2] = (float)idx; r[3] = first; r[4] = second; r[5] = (float)who;
+    }
 }
+#endif
 
 // S and Mi are held as ONE combined 64x64 array A:
 //     A[i][k] = S[i][k]   for k <= i   (Schur complement, lower triangle)
@@ -426,45 +447,37 @@ template <> __device__ __forceinline__ float tiny_if<float>(float v, bool c) { r
 
 template <typename T>
 static __device__ __forceinline__ void pivot_block(int p, T (&nx)[4], T (&cv)[4], T (&hsr)[4], T (&hsr2)[4],
+                                                    T (&sm1)[4][4], T (&sm2)[4][4],
                                                     T* __restrict__ hs_row, T* __restrict__ cs, int i)
 {
     constexpr int LS = SB + 2;
     constexpr int BC = 4;
+    constexpr int NP = SB / BC;
     const int j0 = BC * p;
-    // The gathered columns carry the updates through block p-3 only (the tile waves hand them over BEFORE their
-    // own multiply of block p-2: see TileGroup::step): this wave applies blocks p-2 and p-1 itself.  The 4 x 4
-    // coefficients of a block = its pivot-time columns at the rows of block p, published in `cs` by this wave;
-    // uniform 16-byte LDS reads, in flight together with the gathered columns.  One chain of fused operations
-    // per column (fewest instructions).  Rows of block p-2 and p-1 arrive as zero (their slots restart there);
-    // a row of block p-1 takes nothing from block p-2 (not born yet: reset between the two updates).
+    // The 4 x 4 coefficients of an earlier block's rank-4 update = its pivot-time columns at the rows of block p,
+    // published in `cs` by THIS wave: sm1 (block p-1) and, in the gather-first form, sm2 (block p-2) were requested at
+    // the end of the previous block, behind its publishing stores and ahead of its barrier (below).  One chain of fused
+    // operations per column (fewest instructions).
+#ifdef CIMRGP_GATHER_FIRST        /* the round-4 hand-over: gathered columns carry the updates through block p-3, two self-updates here */
+    // Rows of block p-2 and p-1 arrive as zero (their slots restart there); a row of block p-1 takes nothing from
+    // block p-2 (not born yet: reset between the two updates).
     if (p > 1) {
-        const T* sp = &cs[j0 * LS + j0 - 2 * BC];
-        T sm[BC][BC];
-#pragma unroll
-        for (int t2 = 0; t2 < BC; ++t2)
-#pragma unroll
-            for (int t = 0; t < BC; ++t) sm[t2][t] = sp[t2 * LS + t];
         const bool rows_prev = (unsigned)(i - (j0 - BC)) < (unsigned)BC;
 #pragma unroll
         for (int t2 = 0; t2 < BC; ++t2) {
             T u = nx[t2];
 #pragma unroll
-            for (int t = 0; t < BC; ++t) u = fma(hsr2[t], sm[t2][t], u);
+            for (int t = 0; t < BC; ++t) u = fma(hsr2[t], sm2[t2][t], u);
             nx[t2] = tiny_if<T>(u, rows_prev);
         }
     }
+#endif
     if (p > 0) {
-        const T* sp = &cs[j0 * LS + j0 - BC];
-        T sm[BC][BC];
-#pragma unroll
-        for (int t2 = 0; t2 < BC; ++t2)
-#pragma unroll
-            for (int t = 0; t < BC; ++t) sm[t2][t] = sp[t2 * LS + t];
 #pragma unroll
         for (int t2 = 0; t2 < BC; ++t2) {
             T u = nx[t2];
 #pragma unroll
-            for (int t = 0; t < BC; ++t) u = fma(hsr[t], sm[t2][t], u);
+            for (int t = 0; t < BC; ++t) u = fma(hsr[t], sm1[t2][t], u);
             nx[t2] = u;
         }
     }
@@ -494,7 +507,31 @@ static __device__ __forceinline__ void pivot_block(int p, T (&nx)[4], T (&cv)[4]
         hs_row[t] = nh[t];
         cp[t] = cv[t];
     }
-    // this wave's own copies of the left operand, for the next two blocks' self-updates: a row of THIS block takes
+    // Round 5: the NEXT block's coefficients are requested here, behind the publishing stores and ahead of the barrier.
+    // (1) They are this wave's own words (rows j0+4 .. j0+7 of the columns just published and of the block before), so
+    //     nothing is waited for that is not there; behind the barrier only the gathered columns remain to be read.
+    // (2) The barrier's wait for these LOADS is what makes the stores above visible to the tile waves that read `hs`
+    //     and `cs` right behind the barrier: the LDS executes a wave's accesses in order, so the loads' data returns
+    //     only after the stores have been performed -- the wait for a store's lgkmcnt alone does not imply that
+    //     (lds_settle in common.hpp has the measurement).  The last block settles on its last word instead.
+    if (p + 1 < NP) {
+        const T* sp = &cs[(j0 + BC) * LS + j0];
+#pragma unroll
+        for (int t2 = 0; t2 < BC; ++t2)
+#pragma unroll
+            for (int t = 0; t < BC; ++t) sm1[t2][t] = sp[t2 * LS + t];
+#ifdef CIMRGP_GATHER_FIRST
+        if (p > 0) {
+#pragma unroll
+            for (int t2 = 0; t2 < BC; ++t2)
+#pragma unroll
+                for (int t = 0; t < BC; ++t) sm2[t2][t] = sp[t2 * LS + t - BC];
+        }
+#endif
+    } else {
+        lds_settle(&cp[BC - 1]);
+    }
+    // this wave's own copies of the left operand, for the next blocks' self-updates: a row of THIS block takes
     // nothing from the pivots above it (its slots right of the block are born at its own pivot)
 #pragma unroll
     for (int t = 0; t < BC; ++t) hsr2[t] = hsr[t];
@@ -515,6 +552,7 @@ static __device__ __forceinline__ void diag_roots(const T* __restrict__ cs, T* _
     constexpr int LS = SB + 2;
     const T d = cs[lane * LS + lane];
     rall[lane] = rsqrt_refined<T>(d);
+    lds_settle(&rall[lane]);                 // every wave reads the roots right behind the next barrier
     const unsigned long long badmask = __ballot(lane < w && !(d > (T)0));
     if (badmask != 0ull && lane == 0) atomicCAS(info, 0, col_base + __ffsll((long long)badmask));
 }
@@ -559,15 +597,17 @@ struct TileGroup {
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[k][r] = cs[((BR0 + k) * 16 + X::crow(lane, r)) * LS + BCOL * 16 + (lane & 15)];
     }
-    // The gather of block p+2 for the pivot wave, THEN block p's rank-4 update of the group's tiles.
-    // Round 4: the gather comes FIRST, i.e. the columns leave with the updates through block p-1 only and the pivot
-    // wave applies two blocks itself.  Handing them over right behind this step's multiplies -- as rounds 1-3 did
-    // -- reads accumulators that a just-issued matrix-core instruction may not have written yet once OTHER waves'
-    // multiplies share the SIMD's matrix core (a four-wave workgroup beside a running trailing update, riders, the
-    // blocks of a batch): FP32, four 8-pass multiplies then sixteen LDS writes, beside an FP32 update: 3-27 % of
-    // whole factorisations wrong, always in rows 62 / 63 of a block's last 4 columns -- the last multiply's last
-    // registers; 800 idle cycles before the writes cured it, the compiler's wait states (counted from issue, for
-    // an uncontended core) did not.  Now the values handed over are a full barrier old.
+    // Block p's rank-4 update of the group's tiles, THEN the gather of block p+2 for the pivot wave (the columns leave
+    // updated through block p; the pivot wave applies block p+1 itself).
+    // History: round 4 met intermittently wrong FP32 factors (3-27 % beside a running FP32 update, always the last
+    // rows of a block's last columns), blamed matrix-core results landing late under contention, and moved the gather
+    // AHEAD of the multiplies (values a barrier old, a second self-update in the pivot wave: +1.6 us per kernel).
+    // Round 5 found the cause (tools/lab/race_probe.hip, HISTORY.md): the gathering wave's LAST one or two ds_write
+    // instructions were not yet in the LDS array when the pivot wave read their words right behind the barrier -- it
+    // read, bit for bit, what those words held two blocks earlier; 1024 idle cycles between the multiplies and the
+    // stores changed nothing, reading the last word back ahead of the barrier cured it (0 of 1999 against 60 of 1999).
+    // So the gather is back behind the multiplies, with that read-back (lds_settle); the round-4 order survives
+    // as -DCIMRGP_GATHER_FIRST for comparison.
     //   right operand = the pivot-time columns at this column block's rows (zero for columns that are final),
     //   left operand per tile = the pivot wave's -A[i][j] / d (a row of the block takes nothing from the pivots
     //   above it: the pivot wave publishes unmasked),
@@ -575,14 +615,37 @@ struct TileGroup {
     //   ahead of the operand reads, so that no join sits between the reads and the multiplies).
     // (no __restrict__ on these: `hs` and `cs` are rewritten by the PIVOT wave between the barriers, at addresses
     // that repeat every second block -- a tile wave that only reads them must not be told they are its own)
-    __device__ __forceinline__ void step(int p, const T* hs, const T* cs, T* pcol, int lane)
+    __device__ __forceinline__ void step(int p, const T* hs, const T* cs, T* pcol, int lane RACE_ARG)
     {
         if (NB == 0) return;
         const int j0 = BC * p, bc0 = j0 >> 4, jb = j0 & 15;
         if (BCOL < bc0) return;                                   // uniform: every column of the group is final
         const int fcol = lane & 15, fk = lane >> 4;
+#if defined(CIMRGP_RACE_DUMP) && !defined(CIMRGP_GATHER_FIRST)
+        if (p > 0 && dslot >= 0 && NB == 4) {
+            // the previous step's gather, one barrier later: the accumulators as they stand now against what went to LDS
+            const int q = p - 1, q0 = BC * q, h0 = q0 + 2 * BC, hbc = h0 >> 4, hjb = h0 & 15;
+            if (q + 2 < NP && BCOL == hbc && fcol >= hjb && fcol < hjb + BC) {
+                const T* pc = pcol + ((q & 1) * SB) * BC + (fcol - hjb);
+                float* out = g_race_buf + (size_t)dslot * RD_WORDS + RD_PIV + (q * 64 + lane) * 32;
+#pragma unroll
+                for (int k = 0; k < NB; ++k)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int grow = (BR0 + k) * 16 + X::crow(lane, r);
+                        out[k * 4 + r] = (float)((grow >= q0 + BC && grow < h0) ? (T)0 : acc[k][r]);
+                        out[16 + k * 4 + r] = (float)pc[grow * BC];
+                    }
+            }
+        }
+#endif
         const int col = BCOL * 16 + fcol;
         const int g0 = j0 + 2 * BC, gbc = g0 >> 4, gjb = g0 & 15;   // block p+2
+#if defined(RACE_TOPSLEEP)   /* the delay right behind the barrier, AHEAD of the zeroing: zeroing -> multiply distance unchanged */
+        __builtin_amdgcn_s_sleep(RACE_TOPSLEEP);
+        asm volatile("" : "+v"(acc[NB - 1]));
+#endif
+#ifdef CIMRGP_GATHER_FIRST
         if (p + 2 < NP && BCOL == gbc && fcol >= gjb && fcol < gjb + BC) {
             T* pc = pcol + ((p & 1) * SB) * BC + (fcol - gjb);
 #pragma unroll
@@ -594,6 +657,7 @@ struct TileGroup {
                     pc[grow * BC] = (grow >= j0 && grow < g0) ? (T)0 : acc[k][r];
                 }
         }
+#endif
 #pragma unroll
         for (int k = 0; k < NB; ++k)
             if (BR0 + k == bc0) {
@@ -603,25 +667,76 @@ struct TileGroup {
                     if (rin >= jb && rin < jb + BC && col >= j0 + BC) acc[k][r] = (T)0;
                 }
             }
+#if defined(RACE_PRESLEEP)   /* a delay AHEAD of the operand reads, BEHIND the vector instructions that zero accumulator entries */
+        __builtin_amdgcn_s_sleep(RACE_PRESLEEP);
+#endif
         const T* hsp = hs + ((p & 1) * SB) * BC + fk;
         T bf = cs[col * LS + j0 + fk];
         T af[NB > 0 ? NB : 1];
 #pragma unroll
         for (int k = 0; k < NB; ++k) af[k] = hsp[((BR0 + k) * 16 + fcol) * BC];
+#ifdef CIMRGP_RACE_DETECT
+        const T bf_first = bf;
+        T af_first[NB > 0 ? NB : 1];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) af_first[k] = af[k];
+#endif
         if (col < j0 + BC) bf = (T)0;
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const int arow = (BR0 + k) * 16 + fcol;
             if (arow > j0 + fk && arow < j0 + BC) af[k] = (T)0;
         }
+#if defined(RACE_VNOP)      /* wait states between the vector instructions that wrote accumulator entries and the multiplies that read them */
+#pragma unroll
+        for (int k = 0; k < NB; ++k) asm volatile("s_nop %1" : "+v"(acc[k]) : "n"(RACE_VNOP));
+#endif
 #pragma unroll
         for (int k = 0; k < NB; ++k) acc[k] = mfma_k4(af[k], bf, acc[k]);
+#ifndef CIMRGP_GATHER_FIRST
+        // the hand-over right behind the multiplies (the columns leave updated through block p)
+#ifdef RACE_NOPS_AFTER       /* idle wait states (16 per s_nop 15) between the multiplies and the LDS writes of their results */
+#pragma unroll
+        for (int z = 0; z < RACE_NOPS_AFTER; ++z)
+#pragma unroll
+            for (int k = 0; k < NB; ++k) asm volatile("s_nop 15" : "+v"(acc[k]));
+#endif
+        if (p + 2 < NP && BCOL == gbc && fcol >= gjb && fcol < gjb + BC) {
+            T* pc = pcol + ((p & 1) * SB) * BC + (fcol - gjb);
+#pragma unroll
+            for (int k = 0; k < NB; ++k)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int grow = (BR0 + k) * 16 + X::crow(lane, r);
+                    pc[grow * BC] = (grow >= j0 + BC && grow < g0) ? (T)0 : acc[k][r];
+                }
+#ifndef CIMRGP_RACE_UNSETTLED       /* (tools/lab/race_probe.hip reproduces the round-4 wrong results without this line) */
+            // the gathering lanes read their LAST word back before the wave may arrive at the barrier: only then are
+            // the stores above in the LDS array for the pivot wave's read right behind it (lds_settle, common.hpp)
+            lds_settle(pc + ((BR0 + NB - 1) * 16 + X::crow(lane, 3)) * BC);
+#endif
+        }
+#endif
+#ifdef CIMRGP_RACE_DETECT
+        {
+            // the operands again, hundreds of cycles behind the barrier (block p's hs / cs entries are not rewritten before the next barrier)
+            const volatile T* hv = hsp;
+            const volatile T* cv2 = cs;
+            const T bf2 = cv2[col * LS + j0 + fk];
+            if (__float_as_int((float)bf2) != __float_as_int((float)bf_first)) race_note(1, p, lane, BCOL, (float)bf_first, (float)bf2, BCOL);
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const T a2 = hv[((BR0 + k) * 16 + fcol) * BC];
+                if (__float_as_int((float)a2) != __float_as_int((float)af_first[k])) race_note(0, p, lane, BR0 + k, (float)af_first[k], (float)a2, BCOL);
+            }
+        }
+#endif
     }
 };
 
 // one tile wave's whole pivot loop (two groups; the second may be empty)
 template <typename T, int NB, int BCOL, int BR0, int NB2 = 0, int BCOL2 = 0, int BR02 = 0>
-static __device__ __forceinline__ void tile_wave_loop(const T* hs, const T* cs, T* pcol, int lane)
+static __device__ __forceinline__ void tile_wave_loop(const T* hs, const T* cs, T* pcol, int lane RACE_ARG)
 {
     TileGroup<T, NB, BCOL, BR0> ga;
     TileGroup<T, NB2, BCOL2, BR02> gb;
@@ -633,8 +748,8 @@ static __device__ __forceinline__ void tile_wave_loop(const T* hs, const T* cs, 
 #if defined(DIAG_EXP) && DIAG_EXP == 1
         continue;
 #endif
-        ga.step(p, hs, cs, pcol, lane);
-        if (NB2 > 0) gb.step(p, hs, cs, pcol, lane);
+        ga.step(p, hs, cs, pcol, lane RACE_PASS);
+        if (NB2 > 0) gb.step(p, hs, cs, pcol, lane RACE_PASS);
     }
 }
 
@@ -649,11 +764,22 @@ static __device__ __forceinline__ void diag_tail_lds(int tw, bool pivot, T* __re
     constexpr int NP = SB / BC;
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = lane;
+#ifdef CIMRGP_RACE_DUMP
+    __shared__ int race_slot_s;
+    if (tid == 0) race_slot_s = (blockIdx.y == 0 && g_race_buf) ? atomicAdd(&g_race_slot, 1) : -1;
+    __syncthreads();
+    const int dslot = race_slot_s;
+#endif
     if (pivot) {
         // ---- pivot wave: the recurrence and nothing else
         T cv[BC], hsr[BC], hsr2[BC];                 // this row's block columns, left operands of the last two blocks
+        T sm1[BC][BC], sm2[BC][BC];                  // coefficients of the self-updates, requested one block ahead (pivot_block)
 #pragma unroll
-        for (int t = 0; t < BC; ++t) { cv[t] = (T)0; hsr[t] = (T)0; hsr2[t] = (T)0; }
+        for (int t = 0; t < BC; ++t) {
+            cv[t] = (T)0; hsr[t] = (T)0; hsr2[t] = (T)0;
+#pragma unroll
+            for (int t2 = 0; t2 < BC; ++t2) { sm1[t][t2] = (T)0; sm2[t][t2] = (T)0; }
+        }
         T first[3][BC];                              // blocks 0, 1 and 2 straight from S (zero above the diagonal)
 #pragma unroll
         for (int b = 0; b < 3; ++b)
@@ -664,7 +790,11 @@ static __device__ __forceinline__ void diag_tail_lds(int tw, bool pivot, T* __re
         for (int p = 0; p < NP; ++p) {
             if (p == 8) STAMPW(16, DG_TW);
             T nx[BC];
+#ifndef CIMRGP_GATHER_FIRST
+            if (p < 2) {
+#else
             if (p < 3) {
+#endif
 #pragma unroll
                 for (int t = 0; t < BC; ++t) nx[t] = (p == 0) ? first[0][t] : (p == 1) ? first[1][t] : first[2][t];
             } else {
@@ -673,8 +803,46 @@ static __device__ __forceinline__ void diag_tail_lds(int tw, bool pivot, T* __re
 #pragma unroll
                 for (int t = 0; t < BC; ++t) nx[t] = gp[t];
             }
+#ifdef CIMRGP_RACE_DUMP
+            T nx0[BC];
+#pragma unroll
+            for (int t = 0; t < BC; ++t) nx0[t] = nx[t];
+#endif
+#ifdef CIMRGP_RACE_PDUMP
+            if (g_race_pbuf != nullptr && blockIdx.y == 0) {
+                float* out = g_race_pbuf + ((((col_base >> 6) & 3) * 16 + p) * 64 + i) * 4;
+#pragma unroll
+                for (int t = 0; t < BC; ++t) out[t] = (float)nx[t];
+            }
+#endif
+#ifdef CIMRGP_RACE_DETECT
+            T nx_first[BC];
+#pragma unroll
+            for (int t = 0; t < BC; ++t) nx_first[t] = nx[t];
+#endif
 #if !defined(DIAG_EXP) || DIAG_EXP != 2      /* timing-only builds of tools/diag_probe.hip: 1 = tile waves idle, 2 = pivot wave idle */
-            pivot_block<T>(p, nx, cv, hsr, hsr2, &hs[((p & 1) * SB + i) * BC], cs, i);
+            pivot_block<T>(p, nx, cv, hsr, hsr2, sm1, sm2, &hs[((p & 1) * SB + i) * BC], cs, i);
+#endif
+#ifdef CIMRGP_RACE_DETECT
+#ifndef CIMRGP_GATHER_FIRST
+            if (p >= 2) {
+#else
+            if (p >= 3) {
+#endif
+                const volatile T* gv = &pcol[((p & 1) * SB + i) * BC];
+#pragma unroll
+                for (int t = 0; t < BC; ++t) {
+                    const T g2 = gv[t];
+                    if (__float_as_int((float)g2) != __float_as_int((float)nx_first[t])) race_note(2, p, i, t, (float)nx_first[t], (float)g2, 0);
+                }
+            }
+#endif
+#ifdef CIMRGP_RACE_DUMP
+            if (dslot >= 0) {
+                float* out = g_race_buf + (size_t)dslot * RD_WORDS + (p * 64 + i) * 8;
+#pragma unroll
+                for (int t = 0; t < BC; ++t) { out[t] = (float)nx0[t]; out[4 + t] = (float)cv[t]; }
+            }
 #endif
             lds_barrier();
             if (p == 8) STAMPW(20, DG_TW);
@@ -684,16 +852,16 @@ static __device__ __forceinline__ void diag_tail_lds(int tw, bool pivot, T* __re
         lds_barrier();
         for (int p = 0; p < NP; ++p) lds_barrier();
     } else if (NTW == 6) {
-        if (tw == 0)      tile_wave_loop<T, 2, 3, 0>(hs, cs, pcol, lane);
-        else if (tw == 1) tile_wave_loop<T, 2, 3, 2>(hs, cs, pcol, lane);
-        else if (tw == 2) tile_wave_loop<T, 2, 2, 0>(hs, cs, pcol, lane);
-        else if (tw == 3) tile_wave_loop<T, 2, 2, 2>(hs, cs, pcol, lane);
-        else if (tw == 4) tile_wave_loop<T, 4, 1, 0>(hs, cs, pcol, lane);
-        else              tile_wave_loop<T, 4, 0, 0>(hs, cs, pcol, lane);
+        if (tw == 0)      tile_wave_loop<T, 2, 3, 0>(hs, cs, pcol, lane RACE_PASS);
+        else if (tw == 1) tile_wave_loop<T, 2, 3, 2>(hs, cs, pcol, lane RACE_PASS);
+        else if (tw == 2) tile_wave_loop<T, 2, 2, 0>(hs, cs, pcol, lane RACE_PASS);
+        else if (tw == 3) tile_wave_loop<T, 2, 2, 2>(hs, cs, pcol, lane RACE_PASS);
+        else if (tw == 4) tile_wave_loop<T, 4, 1, 0>(hs, cs, pcol, lane RACE_PASS);
+        else              tile_wave_loop<T, 4, 0, 0>(hs, cs, pcol, lane RACE_PASS);
     } else {
-        if (tw == 0)      tile_wave_loop<T, 4, 3, 0>(hs, cs, pcol, lane);
-        else if (tw == 1) tile_wave_loop<T, 4, 2, 0>(hs, cs, pcol, lane);
-        else              tile_wave_loop<T, 4, 1, 0, 4, 0, 0>(hs, cs, pcol, lane);
+        if (tw == 0)      tile_wave_loop<T, 4, 3, 0>(hs, cs, pcol, lane RACE_PASS);
+        else if (tw == 1) tile_wave_loop<T, 4, 2, 0>(hs, cs, pcol, lane RACE_PASS);
+        else              tile_wave_loop<T, 4, 1, 0, 4, 0, 0>(hs, cs, pcol, lane RACE_PASS);
     }
     STAMP(3);
     __syncthreads();
@@ -736,6 +904,7 @@ static __device__ __forceinline__ void diag_tail(typename Mx<T>::acc_t (&acc)[2]
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 cs[(br * 16 + X::crow(lane, r)) * LS + (2 * ch + c) * 16 + (lane & 15)] = acc[c][r];
+        lds_settle(&cs[(br * 16 + X::crow(lane, 3)) * LS + (2 * ch + 1) * 16 + (lane & 15)]);
     }
     lds_barrier();
     diag_tail_lds<T, NINE_TW, DG_NT>(nine_tile_wave(g), g == DG_TW, pcol, hs, cs, rall, D, ld, w, inv, info, col_base);
@@ -781,7 +950,7 @@ void k_diag64(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow, 
     const int br = (g >> 1) & 3, ch = g & 1;
     const int fcol = lane & 15;
     // latency-bound chain running next to MFMA-bound update workgroups: win issue arbitration
-    __builtin_amdgcn_s_setprio(3);
+    CHAIN_SETPRIO();
 
     STAMP(0);
     // the block's own elements are requested first (they depend on nothing), so that their round
@@ -883,7 +1052,7 @@ static __device__ __forceinline__ void trsm64_body(unsigned char* smem, T* __res
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rt = wave & 1, ch = wave >> 1;
-    __builtin_amdgcn_s_setprio(3);               // panel chain: ahead of co-resident update waves
+    CHAIN_SETPRIO();               // panel chain: ahead of co-resident update waves
     const T* Pprev = Prow - kprev;               // the panel's earlier columns of the same rows
 
     STAMP(8);
@@ -964,7 +1133,7 @@ static __device__ __forceinline__ void trsm64_group(unsigned char* smem, T* __re
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rt = wave & 1, ch = wave >> 1;
-    __builtin_amdgcn_s_setprio(3);
+    CHAIN_SETPRIO();
     const T* Pprev = Prow - kprev;
     v4u ra[TR * TL::CPR / 256], rb[SB * TL::CPR / 256], rinv[SB * TL::CPR / 256];
 #pragma unroll
@@ -1120,7 +1289,7 @@ void k_link(T* __restrict__ A, int64_t ld, int n, int c0, int k0, int wn,
     const bool tile_wave = g < DG_TW;
     const int br = (g >> 1) & 3, ch = g & 1;
     const int fcol = lane & 15;
-    __builtin_amdgcn_s_setprio(3);
+    CHAIN_SETPRIO();
     T* Arow = A + (int64_t)r0 * ld;                  // the next diagonal block's rows
     T* D = Arow + r0;
 
@@ -1271,6 +1440,8 @@ static __device__ __forceinline__ void schur_to_lds(T* __restrict__ cs, const T 
             if (row < w && col <= row) v = dval[c][r] - sub[c][r];
             cs[row * LS + col] = v;
         }
+    // the other waves read these words right behind the caller's barrier: read the last one back first (lds_settle)
+    lds_settle(&cs[(wave * 16 + X::crow(lane, 3)) * LS + 3 * 16 + (lane & 15)]);
 }
 
 template <typename T>
@@ -1296,7 +1467,7 @@ void k_diag64q(T* __restrict__ D, int64_t ld, int w, const T* __restrict__ Lrow,
     __shared__ __attribute__((aligned(16))) unsigned char rall_[DiagLds<T>::RALL];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    __builtin_amdgcn_s_setprio(3);
+    CHAIN_SETPRIO();
     T dval[4][4];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
@@ -1389,7 +1560,7 @@ void k_linkq(T* __restrict__ A, int64_t ld, int n, int c0, int k0, int wn,
     unsigned char* bufB = smem + SB * TL::LROW;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    __builtin_amdgcn_s_setprio(3);
+    CHAIN_SETPRIO();
     T* Arow = A + (int64_t)r0 * ld;
     T* D = Arow + r0;
 

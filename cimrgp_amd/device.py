@@ -192,13 +192,16 @@ def solve_lt_batched(karena, n, ld, ws_arena, z):
     return z
 
 
-#: work areas of cimrgp_layer_fit (carried target rows, solve scratch) per (device, dtype, batch, q, n): the fit of a layer
-#: is enqueue-only, so they are not allocated per call; a new shape replaces the cached one (O(batch q n) elements)
+#: work areas of cimrgp_layer_fit (carried target rows, solve scratch) per (device, dtype, STREAM): the fit of a layer
+#: is enqueue-only, so they are not allocated per call; a new shape replaces the cached one (O(batch q n) elements).
+#: Keyed by the stream the call is enqueued on (round 5): two fits on two streams -- two models, two
+#: threads, a caller's stream pool -- must not share the carried rows; within one stream the calls are ordered, and the
+#: caching allocator frees a replaced area in that same stream's order.
 _LAYER_WORK = {}
 
 
 def _layer_work_areas(batch, q, n, ldr, dtype, device):
-    key = (str(device), dtype)
+    key = (str(device), dtype, int(_stream() or 0))
     shape = (batch, q, n)
     hit = _LAYER_WORK.get(key)
     if hit is None or hit[0] != shape:

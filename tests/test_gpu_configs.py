@@ -340,10 +340,13 @@ def test_bench_step_under_rccl_world_of_one():
     rccl1 = _run_bench(["--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--nccl-world1", "--rows-queues", "1"])
     print("ms_per_step  plain %.3f | nccl world 1, two rows queues %.3f | one rows queue %.3f"
           % (plain["ms_per_step"], rccl2["ms_per_step"], rccl1["ms_per_step"]))
-    assert plain["config"]["backend"] == "none" and rccl2["config"]["backend"] == "nccl"
+    # round 5: the step's collective is the C ABI's (cimrgp_allreduce_sum) on the step's own solve queue -- no RCCL stream of
+    # torch's in the process (the fifth queue that cost the pipelined step its gain in round 4); control plane gloo
+    assert plain["config"]["backend"] == "none" and rccl2["config"]["backend"].startswith("rccl through the C ABI")
     assert rccl2["config"]["rows_queues"] == 2 and rccl1["config"]["rows_queues"] == 1
-    # a live RCCL communicator (its stream included) must not disturb the step: within 15 % of the plain run
-    assert rccl2["ms_per_step"] < 1.15 * plain["ms_per_step"]
+    # a live RCCL communicator must not disturb the step: within 5 % of the plain run (profiles/r05_rccl_world_of_one.jsonl: 1 %)
+    assert rccl2["ms_per_step"] < 1.05 * plain["ms_per_step"]
+    assert rccl2["reduce_selfcheck_max_abs_diff"] == 0.0
     # the timed step is ONE C call; the collective is started at its end and hidden behind the next step: a step that
     # waits for it inside (drained_step_ms) is reported beside the headline and may not cost more than 1 ms extra
     assert plain["reduce_overlapped"] is False and plain["drained_step_ms"] is None

@@ -618,6 +618,79 @@ def test_block_posterior_staged_pipeline_matches_the_one_stream_call(dev, n, ns,
     assert all(int(b["info"].item()) == 0 for b in sets)
 
 
+def test_block_posterior_staged_two_stream_pairs_on_one_device(dev):
+    """Round 5: TWO caller stream pairs on one device alternate staged calls, each pair over its own two
+    buffer sets in rotation with nothing ordered by the caller, then a plain call reuses a set whose solve stage may
+    still be running.  The library keeps one in-flight record per (stream, stream_solve) pair and per buffer set
+    (round 4: one per device, so each pair overwrote the other's and both safety nets were lost).  Every block's
+    posterior against the oracle; the regions of a layer are independent (src/Posteriors.py:35-59)."""
+    tdt = torch.float64
+    n, ns, q = 5376, 64, 2                 # above the one-queue size: each pair's stream gets a look-ahead context
+    ell, sf2, noise = 0.05, 1.1, 0.02
+    rng = np.random.default_rng(55)
+    nper = 4
+    blocks = []
+    for b in range(2 * nper + 1):
+        x = np.sort(rng.uniform(-2.0, 2.0, size=(n, 1)), axis=0)
+        y = np.stack([np.sin(3 * x[:, 0] + c + b) for c in range(q)], axis=1) + 0.1 * rng.normal(size=(n, q))
+        xs = rng.uniform(-2.0, 2.0, size=(ns, 1))
+        blocks.append((x, y, xs))
+    dblocks = [tuple(dev.to_device(a, tdt, "cuda") for a in blk) for blk in blocks]
+
+    def buffers():
+        return dict(kbuf=dev.alloc_matrix(n, n, tdt, "cuda"), wbuf=dev.alloc_matrix(ns + q, n, tdt, "cuda"),
+                    ws=dev.potrf_workspace(n, tdt, "cuda"), info=torch.zeros(1, dtype=torch.int32, device="cuda"),
+                    alpha=torch.zeros((n, q), dtype=tdt, device="cuda"), z=torch.zeros((n, q), dtype=tdt, device="cuda"),
+                    scratch=torch.empty(2 * q * n, dtype=tdt, device="cuda"))
+    # earlier tests of this process may have used up the device's eight look-ahead contexts (a ninth caller stream
+    # shares one by hash and has no solve queue of its own): start from none
+    torch.cuda.synchronize()
+    from cimrgp_amd import _lib
+    _lib.check(_lib.load().cimrgp_shutdown(), "cimrgp_shutdown")
+    pairs = []
+    for _ in range(2):
+        st = torch.cuda.Stream()
+        sq = dev.solve_queue(st)
+        assert sq.cuda_stream != st.cuda_stream
+        pairs.append((st, sq, [buffers(), buffers()]))
+    assert pairs[0][1].cuda_stream != pairs[1][1].cuda_stream
+    means = [torch.zeros((ns, q), dtype=tdt, device="cuda") for _ in blocks]
+    vars_ = [torch.zeros(ns, dtype=tdt, device="cuda") for _ in blocks]
+    alphas = [None] * len(blocks)
+    infos = [None] * len(blocks)
+    torch.cuda.synchronize()
+    for i in range(2 * nper):
+        st, sq, sets = pairs[i % 2]
+        b = sets[(i // 2) % 2]
+        xd, yd, xsd = dblocks[i]
+        dev.block_posterior(xd, yd, xsd, ell, sf2, noise, b["kbuf"], b["wbuf"], b["ws"], b["info"], b["alpha"], b["z"],
+                            means[i], vars_[i], scratch=b["scratch"], streams=(st, st, sq))
+        if i == 2 * nper - 2:
+            continue                                 # its set is reused by the plain call below with NOTHING in between
+        with torch.cuda.stream(sq):                  # behind this call's solve stage, ahead of the set's next use
+            alphas[i] = b["alpha"].clone()
+            infos[i] = b["info"].clone()
+    # a PLAIN call on pair 0's most recently used set, on a third stream, right behind the staged call that used it
+    i = 2 * nper
+    st3 = torch.cuda.Stream()
+    b = pairs[0][2][((2 * nper - 2) // 2) % 2]
+    xd, yd, xsd = dblocks[i]
+    with torch.cuda.stream(st3):
+        dev.block_posterior(xd, yd, xsd, ell, sf2, noise, b["kbuf"], b["wbuf"], b["ws"], b["info"], b["alpha"], b["z"],
+                            means[i], vars_[i], scratch=b["scratch"])
+        alphas[i] = b["alpha"].clone()
+        infos[i] = b["info"].clone()
+    torch.cuda.synchronize()
+    for i, (x, y, xs) in enumerate(blocks):
+        fit = oracle.block_fit(x, y, ell, sf2, noise)
+        om, ov = oracle.block_predict(x, fit, xs, ell, sf2, True)
+        if alphas[i] is not None:
+            assert int(infos[i].item()) == 0
+            assert _relerr(alphas[i].cpu().numpy(), fit["alpha"]) < 1e-8, i
+        assert _relerr(means[i].cpu().numpy(), om) < 1e-8, i
+        assert float(np.max(np.abs(vars_[i].cpu().numpy() - ov))) / sf2 < 1e-9, i
+
+
 @pytest.mark.parametrize("n,ns,q,d", [(300, 70, 2, 2), (1100, 130, 3, 1), (5377, 70, 2, 1), (6000, 260, 1, 2)])
 def test_block_posterior_one_call_matches_the_separate_calls_and_the_oracle(dev, n, ns, q, d):
     """cimrgp_block_posterior: Gram, factorisation with the cross-Gram rows and the targets carried, backward solve,

@@ -195,7 +195,7 @@ def test_two_panel_far_updates_n10240(ca):
     assert float((back - w0).abs().max() / w0.abs().max()) < 1e-9
 
 
-def _two_rank_worker(rank, world, port, out_dir):
+def _two_rank_worker(rank, world, port, out_dir, shared=False):
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -213,38 +213,49 @@ def _two_rank_worker(rank, world, port, out_dir):
     xs = np.sort(rng.uniform(-2, 2, size=(ns, 1)), axis=0)
     kernels = [ca.RBFKernel(l=1.0 / 2 ** j, sf=1.0) for j in range(res + 1)]
     model = ca.MultiResolutionGaussianProcess([x, y], index_set_obj=ca.IndexSetUniform(n, res, 2),
-                                              spectral_density_obj=kernels)
+                                              spectral_density_obj=kernels, bias_region_specific=not shared,
+                                              noise_region_specific=not shared)
     assert (model.rank, model.world_size) == (rank, world)
     owned = [len(model._owned(j)) for j in range(res + 1)]
     model.fit()
     mean, var = model.get_predicted_mean_and_var(xs, ca.IndexSetUniform(ns, res, 2))
+    # the fine layers' equal-sized blocks must have gone through the batched fit on every rank (a view
+    # into a shared buffer at an odd offset used to disable it on the local layers)
+    batched = [len(p.batches) for p in model.posterior_obj]
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), mean=mean, var=var, owned=np.array(owned),
-             f_bar=model._f_bar_final.cpu().numpy(), x=x, y=y, xs=xs)
+             f_bar=model._f_bar_final.cpu().numpy(), x=x, y=y, xs=xs, local_from=model._local_from, batched=np.array(batched))
     td.destroy_process_group()
 
 
-def test_two_rank_sharded_model_on_gpu(ca, tmp_path):
+@pytest.mark.parametrize("shared", [False, True])
+def test_two_rank_sharded_model_on_gpu(ca, tmp_path, shared):
     """N > 1 path end to end on real kernels: blocks sharded over 2 ranks, per-layer residual
-    all-reduce, one fused [mean | var] reduce; every rank must hold the single-process result."""
+    all-reduce, one fused [mean | var] reduce; every rank must hold the single-process result.
+    shared: bias and noise shared by the regions of a layer (bias_region_specific = noise_region_specific = False,
+    MRGP.py:27-28) -- statistics over the WHOLE latent function, which nested ownership leaves valid on a rank's own
+    ranges only: every layer must then be exchanged (round 5)."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), shared), nprocs=2, join=True)
     g0 = np.load(os.path.join(str(tmp_path), "rank0.npz"))
     g1 = np.load(os.path.join(str(tmp_path), "rank1.npz"))
     x, y, xs = g0["x"], g0["y"], g0["xs"]
     n, ns, res = x.shape[0], xs.shape[0], 3
     xn, _, mu, sd = oracle.normalize_inputs(x)
     specs = [oracle.DenseLayerSpec(1.0 / 2 ** j, 1.0, None) for j in range(res + 1)]
-    omodel, f_bar = oracle.mrgp_fit(xn, y, oracle.index_bounds_uniform(n, res, 2), specs)
+    omodel, f_bar = oracle.mrgp_fit(xn, y, oracle.index_bounds_uniform(n, res, 2), specs, not shared, not shared)
     omean, ovar = oracle.mrgp_predict(xn, omodel, specs, (xs - mu) / sd, oracle.index_bounds_uniform(ns, res, 2))
     for g in (g0, g1):
         assert _relerr(g["mean"], omean) < 1e-7
         assert _relerr(g["var"], ovar) < 1e-6
         assert _relerr(g["f_bar"], f_bar) < 1e-7
+        # nested ownership: layers 1.. are local (2 ranks: the anchor is layer 1) unless the statistics are shared
+        assert int(g["local_from"]) == (4 if shared else 1)
+        assert g["batched"].tolist()[2:] == [1, 1]          # 2 and 4 equal blocks per rank: one batched fit each
     # layer 0 has one block (rank 0), finer layers are split evenly
     assert g0["owned"].tolist() == [1, 1, 2, 4] and g1["owned"].tolist() == [0, 1, 2, 4]
 

@@ -53,7 +53,7 @@ if want configs; then
     CIMRGP_BENCH_REHEARSAL=gloo python3 bench.py --config 4 --gpus 2 --n 8192 --steps 2 --warmup 1 > $out/${tag}_config4_n8192_two_ranks_gloo.json 2>> $out/${tag}_config4.err
 fi
 if want rccl; then
-    for mode in "" "--nccl-world1" "--nccl-world1 --rows-queues 1"; do
+    for mode in "" "--nccl-world1" "--nccl-world1 --comm torch" "--nccl-world1 --rows-queues 1"; do
         python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline $mode 2>/dev/null | tail -1
     done > $out/${tag}_rccl_world_of_one.jsonl
 fi
