@@ -51,6 +51,15 @@ template <> struct Mx<double> {
         double db = __hiloint2double((int)b.y, (int)b.x);
         return __builtin_amdgcn_mfma_f64_16x16x4f64(da, db, c, 0, 0, 0);
     }
+    // c - a b: the FP64 matrix-core instruction negates an operand itself (on gfx940+ the builtin's last argument is
+    // neg:[A, B, C] for v_mfma_f64_*: the assembler prints `neg:[1,0,0]`), so no vector instruction is spent on the sign
+    // (round 5: the update kernels flipped the sign bit of every A fragment with a v_xor -- 16 per stage and wave, each
+    // taking a vector issue slot the next multiply had to wait for).  Bit-identical: negation is exact.
+    static __device__ __forceinline__ acc_t mma_neg(uint2 a, uint2 b, acc_t c) {
+        double da = __hiloint2double((int)a.y, (int)a.x);
+        double db = __hiloint2double((int)b.y, (int)b.x);
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(da, db, c, 0, 0, 1);
+    }
 };
 
 template <> struct Mx<float> {
@@ -65,6 +74,8 @@ template <> struct Mx<float> {
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
         return c;
     }
+    // c - a b (the FP32 instruction has no operand negation: its last field selects lane groups): flip the sign bits
+    static __device__ __forceinline__ acc_t mma_neg(uint2 a, uint2 b, acc_t c) { return mma(neg(a), b, c); }
 };
 
 template <typename T>

@@ -145,7 +145,8 @@ static __device__ __forceinline__ int pers_tile_number(int w, int i, int grid, i
 // (K = 16 stages of 128 bytes: 256 doubles / 512 floats): event e covers accumulator tile
 // (mi, ni) = (e >> 2, (e >> 1) & 1), values r = 2 (e & 1) + {0, 1} (two rows of 16 lanes x 8 bytes = two
 // 128-byte lines per row tile).  An event stores the finished values of the previous tile and requests the
-// next tile's into two staging registers, which are moved into the accumulator set TWO events later.
+// next tile's straight into the registers just stored from (round 5; rounds 3-4 went through two staging
+// registers and four moves per event).
 // The 16 stages of a tile are fully unrolled: every register index is a compile-time constant and the
 // whole pass is straight-line code, so the compiler counts the memory instructions exactly -- the
 // wait for stage g+1's operands at the top of stage g leaves the 4 C accesses issued behind them in
@@ -175,6 +176,42 @@ static __device__ __forceinline__ int pers_tile_number(int w, int i, int grid, i
 #define PERS_BARRIER_A() lds_barrier()              /* stage kt+1's LDS writes are done: s_waitcnt lgkmcnt(0); s_barrier */
 #define PERS_BARRIER_B() lds_barrier_nowait()       /* every wave has consumed stage kt's fragments: s_barrier alone */
 #endif
+#if PERS_EXP == 20          /* diagnostic build (tools/lab/pers_stamps.py): shader-clock stamps of wave 0 at every stage's first barrier, first 8 tiles of every workgroup */
+__device__ long long g_pers_stamp[256][8 * 16 + 2];
+#define PERS_STAMP(slot_) do { if (tid == 0 && it < 8) g_pers_stamp[wg & 255][slot_] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PERS_STAMP_EXIT() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (tid == 0) g_pers_stamp[wg & 255][129] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PERS_STAMP(slot_) do { } while (0)
+#define PERS_STAMP_EXIT() do { } while (0)
+#endif
+// A tile of C as a raw buffer: base = the tile's first element (wave-uniform), no stride, the largest extent (a lane's
+// offsets stay below 2^31: the launcher checks 128 rows of C against it).
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const void* p)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+typedef unsigned int cbuf_u2 __attribute__((ext_vector_type(2)));
+template <typename T> static __device__ __forceinline__ T cbuf_load(__amdgpu_buffer_rsrc_t r, int voff, int soff);
+template <> __device__ __forceinline__ double cbuf_load<double>(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    const cbuf_u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
+template <> __device__ __forceinline__ float cbuf_load<float>(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+template <typename T> static __device__ __forceinline__ void cbuf_store(T v, __amdgpu_buffer_rsrc_t r, int voff, int soff);
+template <> __device__ __forceinline__ void cbuf_store<double>(double v, __amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    const cbuf_u2 u = {(unsigned)__double2loint(v), (unsigned)__double2hiint(v)};
+    __builtin_amdgcn_raw_buffer_store_b64(u, r, voff, soff, 0);
+}
+template <> __device__ __forceinline__ void cbuf_store<float>(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+
 constexpr int PERS_THREADS = 512;
 constexpr int PERS_STAGES = 16;
 
@@ -214,6 +251,9 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
     // this lane's first element of its wave's 64 x 32 share, inside a tile
     const int lrow0 = wr * 64 + X::crow(lane, 0), lcol0 = wc * 32 + (lane & 15);
     const int coff = lrow0 * (int)ldc + lcol0;
+    // this lane's byte offset from a tile's first element (constant), and the bytes of a row of C
+    const int cbyte0 = coff * (int)sizeof(T);
+    const int row_bytes = (int)ldc * (int)sizeof(T);
 
     // heads > 0: head-first order (above); every one of the first `heads` tiles, once STORED, adds 1 to *flag
     auto decode = [&](int q, int& i_, int& j_) {
@@ -230,6 +270,12 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
             __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
+#if PERS_EXP == 22      /* experiment: static priority for the second-dispatched half of the waves */
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
+#if PERS_EXP == 20
+    if (tid == 0) g_pers_stamp[wg & 255][128] = __builtin_amdgcn_s_memtime();
+#endif
     int it = 0;                                   // this workgroup's tile counter
     int t = pers_tile_number(wg, it, grid, ntiles);
     if (t < 0) return;
@@ -242,10 +288,15 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
     T* c_prv = c_cur;
     // first-class vectors: arrays of HIP's uint4 struct filled from global memory can stay in scratch
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+#if PERS_EXP == 21      /* experiment: operands requested TWO stages ahead (two register sets) */
+    v4u ra2[2][2], rb2[2][2];
+#define ra ra2[0]
+#define rb rb2[0]
+#else
     v4u ra[2], rb[2];
+#endif
     uint2 fa[2][4], fb[2][2];                                // two fragment sets: k-step s+1 is read while s is multiplied
     acc_t acc0[4][2], acc1[4][2];
-    T tld[2][2];                                             // next tile's values in flight (two events deep)
 
 #define PERS_GLOAD(ap_, bp_, kt_)                                                  \
     {                                                                              \
@@ -276,9 +327,8 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
 #define PERS_MMA_NF(cur_, set_)                                                    \
     {                                                                              \
         _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                         \
-            const uint2 an_ = X::neg(fa[set_][mi]);                                \
             _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                       \
-                cur_[mi][ni] = X::mma(an_, fb[set_][ni], cur_[mi][ni]);            \
+                cur_[mi][ni] = X::mma_neg(fa[set_][mi], fb[set_][ni], cur_[mi][ni]); \
         }                                                                          \
     }
 #define PERS_MMA(cur_, set_)  { PERS_MMA_NF(cur_, set_) __builtin_amdgcn_sched_barrier(0); }
@@ -312,7 +362,30 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) acc1[mi][ni] = acc0[mi][ni];
     PERS_SWRITE(0);
+#if PERS_EXP == 21
+#undef ra
+#undef rb
+#define PERS_GLOAD_S(set_, ap_, bp_, kt_)                                          \
+    {                                                                              \
+        _Pragma("unroll") for (int p = 0; p < 2; ++p) {                            \
+            ra2[set_][p] = *reinterpret_cast<const v4u*>((ap_) + (a_off_e[p] + (kt_) * BKE)); \
+            rb2[set_][p] = *reinterpret_cast<const v4u*>((bp_) + (b_off_e[p] + (kt_) * BKE)); \
+        }                                                                          \
+    }
+#define PERS_SWRITE_S(set_, buf_)                                                  \
+    {                                                                              \
+        unsigned char* as_ = smem + (buf_) * 2 * OP_BYTES;                         \
+        unsigned char* bs_ = as_ + OP_BYTES;                                       \
+        _Pragma("unroll") for (int p = 0; p < 2; ++p) {                            \
+            *reinterpret_cast<v4u*>(as_ + (sr + 64 * p) * LROW + sc * 16) = ra2[set_][p]; \
+            *reinterpret_cast<v4u*>(bs_ + (sr + 64 * p) * LROW + sc * 16) = rb2[set_][p]; \
+        }                                                                          \
+    }
+    PERS_GLOAD_S(1, a_cur, b_cur, 1);
+    PERS_GLOAD_S(0, a_cur, b_cur, 2);
+#else
     PERS_GLOAD(a_cur, b_cur, 1);
+#endif
     __syncthreads();
     PERS_FRAGS(0, 0, 0);
 
@@ -322,25 +395,34 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
 #define PERS_EVENT_ONE(oth_, e_)                                                                         \
         if (PERS_EXP != 3) {                    /* event e_ (compile-time after unrolling) */                   \
                 const int mi_ = (e_) >> 2, ne_ = ((e_) >> 1) & 1, r0_ = 2 * ((e_) & 1);                         \
-                if ((e_) >= 2) {                    /* the values requested two events ago have arrived */      \
-                    oth_[((e_) - 2) >> 2][(((e_) - 2) >> 1) & 1][2 * (((e_) - 2) & 1)] = tld[(e_) & 1][0];      \
-                    oth_[((e_) - 2) >> 2][(((e_) - 2) >> 1) & 1][2 * (((e_) - 2) & 1) + 1] = tld[(e_) & 1][1];  \
-                }                                                                                               \
-                const int64_t uo_ = (int64_t)(mi_ * 16 + RS * r0_) * ldc + ne_ * 16;                            \
-                T* sb_ = c_prv + uo_;                                                                           \
+                /* buffer addressing (round 5): the tile's descriptor (SGPRs, rebuilt per tile by scalar code) + this */ \
+                /* lane's constant 32-bit byte offset + a wave-uniform scalar offset for the event: NO vector     */ \
+                /* instruction per access (the 64-bit flat address took a v_lshl_add_u64 for each of the four)    */ \
+                const int so0_ = (mi_ * 16 + RS * r0_) * row_bytes + ne_ * 16 * (int)sizeof(T);                 \
+                const int so1_ = so0_ + RS * row_bytes;                                                         \
                 if (PERS_EXP != 4) {                                                                            \
-                    sb_[coff] = oth_[mi_][ne_][r0_];                                                            \
-                    (sb_ + (int64_t)RS * ldc)[coff] = oth_[mi_][ne_][r0_ + 1];                                  \
+                    cbuf_store<T>(oth_[mi_][ne_][r0_], rs_prv, cbyte0, so0_);                                   \
+                    cbuf_store<T>(oth_[mi_][ne_][r0_ + 1], rs_prv, cbyte0, so1_);                               \
                 }                                                                                               \
-                const T* lb_ = (PERS_EXP == 6) ? c_nxt : c_nxt + uo_;                                           \
-                if (PERS_EXP != 5) {                                                                            \
-                    tld[(e_) & 1][0] = lb_[coff];                                                               \
-                    tld[(e_) & 1][1] = (lb_ + (int64_t)RS * ldc)[coff];                                         \
+                if (PERS_EXP != 5) {            /* straight into the set just stored from: nobody reads it before the next pass */ \
+                    oth_[mi_][ne_][r0_] = cbuf_load<T>(rs_nxt, cbyte0, (PERS_EXP == 6) ? 0 : so0_);             \
+                    oth_[mi_][ne_][r0_ + 1] = cbuf_load<T>(rs_nxt, cbyte0, (PERS_EXP == 6) ? 0 : so1_);         \
                 }                                                                                               \
             }
     /* the stage's events: one (NKT = 16) or two (NKT = 8) */
 #define PERS_EVENT_BLOCK(oth_)                                                                                  \
         { _Pragma("unroll") for (int ev_ = 0; ev_ < EVS; ++ev_) { PERS_EVENT_ONE(oth_, kt * EVS + ev_) } }
+#if PERS_EXP == 21
+#define PERS_STAGE_OPERANDS(kt_)                                                                                \
+            PERS_SWRITE_S(((kt_) + 1) & 1, ((kt_) & 1) ^ 1);                                                    \
+            if ((kt_) + 3 < NKT) PERS_GLOAD_S(((kt_) + 1) & 1, a_cur, b_cur, (kt_) + 3)                         \
+            else                 PERS_GLOAD_S(((kt_) + 1) & 1, a_nxt, b_nxt, (kt_) + 3 - NKT)
+#else
+#define PERS_STAGE_OPERANDS(kt_)                                                                                \
+            PERS_SWRITE(((kt_) & 1) ^ 1);           /* stage kt+1, in registers since the previous stage */     \
+            if ((kt_) + 2 < NKT) PERS_GLOAD(a_cur, b_cur, (kt_) + 2)    /* stage kt+2 -> registers */            \
+            else                 PERS_GLOAD(a_nxt, b_nxt, (kt_) + 2 - NKT)
+#endif
 #define PERS_PASS(cur_, oth_)                                                                                   \
     {                                                                                                           \
         const int tn_ = pers_tile_number(wg, it + 1, grid, ntiles);                                             \
@@ -348,12 +430,11 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
         int ni_ = ti, nj_ = tj;                                                                                 \
         if (has_next) decode(tn_, ni_, nj_);                                                                    \
         const T* c_nxt = C + (int64_t)ni_ * GT * ldc + (int64_t)nj_ * GT;      /* no next tile: this one */     \
+        const __amdgpu_buffer_rsrc_t rs_prv = tile_rsrc(c_prv), rs_nxt = tile_rsrc(c_nxt);                      \
         const T* a_nxt = A + (int64_t)ni_ * GT * lda;                                                           \
         const T* b_nxt = B + (int64_t)nj_ * GT * ldb;                                                           \
         _Pragma("unroll") for (int kt = 0; kt < NKT; ++kt) {                                                    \
-            PERS_SWRITE((kt & 1) ^ 1);              /* stage kt+1, in registers since the previous stage */     \
-            if (kt + 2 < NKT) PERS_GLOAD(a_cur, b_cur, kt + 2)      /* stage kt+2 -> registers */                \
-            else              PERS_GLOAD(a_nxt, b_nxt, kt + 2 - NKT)                                            \
+            PERS_STAGE_OPERANDS(kt)                                                                             \
             if (PERS_EXP != 7 && PERS_EXP != 8) PERS_EVENT_BLOCK(oth_)                                          \
             /* k-step s+1's fragments are requested before k-step s is multiplied (the scheduler is fenced */  \
             /* so that it cannot fold the pairs back into read -> wait -> multiply)                        */  \
@@ -366,14 +447,12 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
             PERS_FRAGS(1, kt & 1, 3);                                                                           \
             PERS_MMA(cur_, 0);                                                                                  \
             PERS_BARRIER_A();                                                    /* stage kt+1 is in LDS */     \
+            PERS_STAMP(it * 16 + kt);                                                                                   \
             PERS_FRAGS(0, (kt & 1) ^ 1, 0);         /* first fragments of stage kt+1 */                         \
             if (PERS_EXP == 8) { PERS_EVENT_BLOCK(oth_) PERS_MMA_NF(cur_, 1); PERS_INTERLEAVE(); }                  \
             else PERS_MMA(cur_, 1);                                                                             \
             PERS_BARRIER_B();                        /* everyone has read stage kt: its buffer may be rewritten */ \
         }                                                                                                       \
-        /* the last two events of the pass: the next tile's C is complete in `oth` */                          \
-        oth_[3][1][0] = tld[0][0]; oth_[3][1][1] = tld[0][1];                                                   \
-        oth_[3][1][2] = tld[1][0]; oth_[3][1][3] = tld[1][1];                                                   \
         if (prev_head) signal_stored();             /* the previous tile's last store went out in this pass */  \
         prev_head = (t < heads);                                                                                \
         c_prv = c_cur;                                                                                          \
@@ -384,6 +463,7 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
                     _Pragma("unroll") for (int r = 0; r < 4; ++r)                                               \
                         (c_cur + ((int64_t)(mi * 16 + RS * r) * ldc + ni * 16))[coff] = cur_[mi][ni][r];        \
             if (prev_head) signal_stored();                                                                     \
+            PERS_STAMP_EXIT();                                                                                  \
             return;                                                                                             \
         }                                                                                                       \
         t = tn_; ti = ni_; tj = nj_; ++it;                                                                      \
@@ -395,6 +475,7 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
         PERS_PASS(acc1, acc0)
     }
 #undef PERS_PASS
+#undef PERS_STAGE_OPERANDS
 #undef PERS_EVENT_BLOCK
 #undef PERS_EVENT_ONE
 #undef PERS_INTERLEAVE
@@ -560,7 +641,8 @@ int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t 
         // factorisation it is slower (3.85 against 3.64 ms at n = 8192): HISTORY.md, round 4.
         constexpr int pers_nkt = (sizeof(T) == 8) ? PERS_STAGES : PERS_STAGES / 2;
         if (want >= 8 && (sizeof(T) == 8 || knobs().gemm_pers_f32) && nkt == pers_nkt && bt.count == 1 && !bt.skip_first && m % 128 == 0 && n % 128 == 0 &&
-            ldc < (1ll << 23) && lda < (1ll << 23) && ldb < (1ll << 23) && (t128 >= knobs().pers_min_tiles || bt.head_first || bt.pers_force)) {
+            ldc < (1ll << 20) && lda < (1ll << 23) && ldb < (1ll << 23) && (t128 >= knobs().pers_min_tiles || bt.head_first || bt.pers_force)) {
+            // (ldc: 128 rows of C stay below 2^31 bytes -- the C stream addresses a tile through a raw buffer with 32-bit offsets)
             const int64_t tm = m / 128, tn = n / 128;
             // head-first launch (the look-ahead's combined head + bulk update): tile (0, 0) is left to the chain
             const int heads = (bt.head_first && lower && tm >= 3) ? (int)(2 * tm - 2) : 0;
@@ -589,6 +671,13 @@ int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t 
     if (t128 < 768 || thin <= 64) return gemm_launch<T, 2>(c, ldc, a, lda, b, ldb, m, n, k, lower, st, bt);
     return gemm_launch<T, 4>(c, ldc, a, lda, b, ldb, m, n, k, lower, st, bt);
 }
+
+#if PERS_EXP == 20
+extern "C" int cimrgp_debug_pers_stamps(long long* out_host)
+{
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_pers_stamp), sizeof(g_pers_stamp)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 template int gemm_nt_sub<double>(double*, int64_t, const double*, int64_t, const double*, int64_t,
                                  int64_t, int64_t, int, bool, hipStream_t, GemmBatch);

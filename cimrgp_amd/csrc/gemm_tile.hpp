@@ -60,10 +60,8 @@ static __device__ __forceinline__ void gemm_tile(unsigned char* smem, T* __restr
 
     // GLOAD only ISSUES the loads (clamped, always valid addresses); every use of the loaded
     // registers (zero-fill of out-of-range rows/columns) is in SWRITE, after the MFMA block,
-    // so the s_waitcnt lands there and the loads fly during the multiply.  The sign flip that
-    // turns the chain into C - A B^T is applied to the A fragments after the LDS read (one
-    // XOR per fragment and 16 MFMAs); flipping the staged registers component-wise makes
-    // hipcc shuffle them right behind the loads and wait there.
+    // so the s_waitcnt lands there and the loads fly during the multiply.  The sign that turns the
+    // chain into C - A B^T is the multiply's own operand negation (Mx<T>::mma_neg).
 #define CIMRGP_GLOAD(kt_)                                                        \
     {                                                                            \
         const int kcol = (kt_) * BKE + sc * X::EPC;                              \
@@ -142,14 +140,14 @@ static __device__ __forceinline__ void gemm_tile(unsigned char* smem, T* __restr
             uint2 a[W], b[W];
 #pragma unroll
             for (int mi = 0; mi < W; ++mi)
-                a[mi] = X::neg(*reinterpret_cast<const uint2*>(as + a_off + mi * 16 * LROW + s * 32));
+                a[mi] = *reinterpret_cast<const uint2*>(as + a_off + mi * 16 * LROW + s * 32);
 #pragma unroll
             for (int ni = 0; ni < W; ++ni)
                 b[ni] = *reinterpret_cast<const uint2*>(bs + b_off + ni * 16 * LROW + s * 32);
 #pragma unroll
             for (int mi = 0; mi < W; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < W; ++ni) acc[mi][ni] = X::mma(a[mi], b[ni], acc[mi][ni]);
+                for (int ni = 0; ni < W; ++ni) acc[mi][ni] = X::mma_neg(a[mi], b[ni], acc[mi][ni]);
         }
         if (more) CIMRGP_SWRITE((kt + 1) & 1, kt + 1);
         __syncthreads();

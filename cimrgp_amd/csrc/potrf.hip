@@ -344,20 +344,7 @@ static __device__ __forceinline__ void run_rider(unsigned char* smem, const Ride
 // Mi[j,:] r_j, r_j = 1/sqrt(S[j][j]); the row operations that reduce S are
 // applied to Mi.
 // ---------------------------------------------------------------------------
-// (lds_barrier: common.hpp)
-#ifdef CIMRGP_RACE_DUMP     /* tools/lab/race_probe.hip only: what the pivot wave read and published, what a gathering wave wrote */
-__device__ float* g_race_buf;                 // [launch slot][RD_WORDS]
-__device__ int g_race_slot;
-constexpr int RD_PIV = 16 * 64 * 8;            // pivot wave, per block and lane: its 4 columns as read, as published
-constexpr int RD_GAT = 16 * 64 * 32;           // gathering tile wave, per step and lane: 16 values as they stand one barrier later, 16 read back from LDS
-constexpr int RD_WORDS = RD_PIV + RD_GAT;
-#define RACE_ARG , int dslot
-#define RACE_PASS , dslot
-#else
-#define RACE_ARG
-#define RACE_PASS
-#endif
-
+// (lds_barrier, lds_settle: common.hpp)
 #ifdef RACE_NOPRIO          /* tools/lab/race_probe.hip only: the chain kernels at the default wave priority */
 #define CHAIN_SETPRIO() do { } while (0)
 #else
@@ -366,19 +353,6 @@ constexpr int RD_WORDS = RD_PIV + RD_GAT;
 #ifdef CIMRGP_RACE_PDUMP    /* tools/lab/race_probe.hip only, the lightest record: what the pivot wave READ as gathered, per block (one 16-byte store per lane) */
 __device__ float* g_race_pbuf;                // [4 sub-blocks of the panel][16 blocks][64 lanes][4]
 #endif
-#ifdef CIMRGP_RACE_DETECT   /* tools/lab/race_probe.hip only: every LDS value a wave takes right behind a barrier is read AGAIN at the end of its step */
-__device__ int g_race_cnt[4];                 // 0: tile wave's left operand (hs), 1: its right operand (cs), 2: pivot wave's gathered columns (pcol)
-__device__ float g_race_rec[3][64][6];        // per kind, first 64 events: block p, lane, index, first value, second value, wave/tile
-static __device__ __forceinline__ void race_note(int kind, int p, int lane, int idx, float first, float second, int who)
-{
-    const int e = atomicAdd(&g_race_cnt[kind], 1);
-    if (e < 64) {
-        float* r = g_race_rec[kind][e];
-        r[0] = (float)p; r[1] = (float)lane; r[2] = (float)idx; r[3] = first; r[4] = second; r[5] = (float)who;
-    }
-}
-#endif
-
 // S and Mi are held as ONE combined 64x64 array A:
 //     A[i][k] = S[i][k]   for k <= i   (Schur complement, lower triangle)
 //     A[i][k] = Mi[k][i]  for k >  i   (unscaled inverse, stored transposed in the upper triangle)
@@ -455,10 +429,10 @@ static __device__ __forceinline__ void pivot_block(int p, T (&nx)[4], T (&cv)[4]
     constexpr int NP = SB / BC;
     const int j0 = BC * p;
     // The 4 x 4 coefficients of an earlier block's rank-4 update = its pivot-time columns at the rows of block p,
-    // published in `cs` by THIS wave: sm1 (block p-1) and, in the gather-first form, sm2 (block p-2) were requested at
+    // published in `cs` by THIS wave: sm1 (block p-1) and sm2 (block p-2) were requested at
     // the end of the previous block, behind its publishing stores and ahead of its barrier (below).  One chain of fused
     // operations per column (fewest instructions).
-#ifdef CIMRGP_GATHER_FIRST        /* the round-4 hand-over: gathered columns carry the updates through block p-3, two self-updates here */
+#ifndef CIMRGP_GATHER_LATE         /* the gathered columns carry the updates through block p-3: two self-updates here */
     // Rows of block p-2 and p-1 arrive as zero (their slots restart there); a row of block p-1 takes nothing from
     // block p-2 (not born yet: reset between the two updates).
     if (p > 1) {
@@ -520,7 +494,7 @@ static __device__ __forceinline__ void pivot_block(int p, T (&nx)[4], T (&cv)[4]
         for (int t2 = 0; t2 < BC; ++t2)
 #pragma unroll
             for (int t = 0; t < BC; ++t) sm1[t2][t] = sp[t2 * LS + t];
-#ifdef CIMRGP_GATHER_FIRST
+#ifndef CIMRGP_GATHER_LATE
         if (p > 0) {
 #pragma unroll
             for (int t2 = 0; t2 < BC; ++t2)
@@ -597,17 +571,24 @@ struct TileGroup {
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[k][r] = cs[((BR0 + k) * 16 + X::crow(lane, r)) * LS + BCOL * 16 + (lane & 15)];
     }
-    // Block p's rank-4 update of the group's tiles, THEN the gather of block p+2 for the pivot wave (the columns leave
-    // updated through block p; the pivot wave applies block p+1 itself).
-    // History: round 4 met intermittently wrong FP32 factors (3-27 % beside a running FP32 update, always the last
-    // rows of a block's last columns), blamed matrix-core results landing late under contention, and moved the gather
-    // AHEAD of the multiplies (values a barrier old, a second self-update in the pivot wave: +1.6 us per kernel).
-    // Round 5 found the cause (tools/lab/race_probe.hip, HISTORY.md): the gathering wave's LAST one or two ds_write
-    // instructions were not yet in the LDS array when the pivot wave read their words right behind the barrier -- it
-    // read, bit for bit, what those words held two blocks earlier; 1024 idle cycles between the multiplies and the
-    // stores changed nothing, reading the last word back ahead of the barrier cured it (0 of 1999 against 60 of 1999).
-    // So the gather is back behind the multiplies, with that read-back (lds_settle); the round-4 order survives
-    // as -DCIMRGP_GATHER_FIRST for comparison.
+    // The gather of block p+2 for the pivot wave, THEN block p's rank-4 update of the group's tiles: the columns leave
+    // with the updates through block p-1 and the pivot wave applies two blocks itself (its coefficients are in
+    // registers by then: pivot_block).
+    // Why this order (rounds 4 and 5; tools/lab/race_probe.hip, HISTORY.md).  With the gather BEHIND the multiplies --
+    // rounds 1-3 -- FP32 factorisations beside a running FP32 update came out wrong in 1.7-3 % of the runs, always in
+    // the last rows of a block's last columns.  Round 4 blamed matrix-core results landing late and moved the gather
+    // ahead; round 5 found what it was: the gathering wave's LAST one or two ds_write instructions -- issued right
+    // ahead of `s_waitcnt lgkmcnt(0); s_barrier` -- were not yet in the LDS array when the pivot wave read their
+    // words right behind the barrier: it read, bit for bit, what the words held two blocks earlier.  1024 idle cycles
+    // between the multiplies and the stores changed nothing (the matrix cores were never late); reading the last
+    // stored word back ahead of the barrier cured it (0 of 1999 runs against 60 of 1999).  The LDS executes one wave's
+    // accesses in issue order, so a LOAD's returned data proves the wave's earlier stores performed; a store's own
+    // lgkmcnt does not prove them visible to another wave.  Here the operand loads below ARE that proof: they are issued
+    // behind the gather's stores (the compiler-only fence keeps them there) and the multiplies need their data, so the
+    // stores have been performed long before this wave reaches the barrier -- by construction, not by timing.
+    // (The same read-back behind the multiplies, -DCIMRGP_GATHER_LATE, is correct too and one self-update shorter in
+    // the pivot wave, but puts the load's round trip on the tile wave's path: 11.5 / 14.6 us per kernel against
+    // 10.7 / 12.3 in this order: profiles/r05_chain_kernels.txt.)
     //   right operand = the pivot-time columns at this column block's rows (zero for columns that are final),
     //   left operand per tile = the pivot wave's -A[i][j] / d (a row of the block takes nothing from the pivots
     //   above it: the pivot wave publishes unmasked),
@@ -615,37 +596,15 @@ struct TileGroup {
     //   ahead of the operand reads, so that no join sits between the reads and the multiplies).
     // (no __restrict__ on these: `hs` and `cs` are rewritten by the PIVOT wave between the barriers, at addresses
     // that repeat every second block -- a tile wave that only reads them must not be told they are its own)
-    __device__ __forceinline__ void step(int p, const T* hs, const T* cs, T* pcol, int lane RACE_ARG)
+    __device__ __forceinline__ void step(int p, const T* hs, const T* cs, T* pcol, int lane)
     {
         if (NB == 0) return;
         const int j0 = BC * p, bc0 = j0 >> 4, jb = j0 & 15;
         if (BCOL < bc0) return;                                   // uniform: every column of the group is final
         const int fcol = lane & 15, fk = lane >> 4;
-#if defined(CIMRGP_RACE_DUMP) && !defined(CIMRGP_GATHER_FIRST)
-        if (p > 0 && dslot >= 0 && NB == 4) {
-            // the previous step's gather, one barrier later: the accumulators as they stand now against what went to LDS
-            const int q = p - 1, q0 = BC * q, h0 = q0 + 2 * BC, hbc = h0 >> 4, hjb = h0 & 15;
-            if (q + 2 < NP && BCOL == hbc && fcol >= hjb && fcol < hjb + BC) {
-                const T* pc = pcol + ((q & 1) * SB) * BC + (fcol - hjb);
-                float* out = g_race_buf + (size_t)dslot * RD_WORDS + RD_PIV + (q * 64 + lane) * 32;
-#pragma unroll
-                for (int k = 0; k < NB; ++k)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int grow = (BR0 + k) * 16 + X::crow(lane, r);
-                        out[k * 4 + r] = (float)((grow >= q0 + BC && grow < h0) ? (T)0 : acc[k][r]);
-                        out[16 + k * 4 + r] = (float)pc[grow * BC];
-                    }
-            }
-        }
-#endif
         const int col = BCOL * 16 + fcol;
         const int g0 = j0 + 2 * BC, gbc = g0 >> 4, gjb = g0 & 15;   // block p+2
-#if defined(RACE_TOPSLEEP)   /* the delay right behind the barrier, AHEAD of the zeroing: zeroing -> multiply distance unchanged */
-        __builtin_amdgcn_s_sleep(RACE_TOPSLEEP);
-        asm volatile("" : "+v"(acc[NB - 1]));
-#endif
-#ifdef CIMRGP_GATHER_FIRST
+#ifndef CIMRGP_GATHER_LATE
         if (p + 2 < NP && BCOL == gbc && fcol >= gjb && fcol < gjb + BC) {
             T* pc = pcol + ((p & 1) * SB) * BC + (fcol - gjb);
 #pragma unroll
@@ -657,6 +616,7 @@ struct TileGroup {
                     pc[grow * BC] = (grow >= j0 && grow < g0) ? (T)0 : acc[k][r];
                 }
         }
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);      // compiler only: the operand loads below stay BEHIND the gather's stores
 #endif
 #pragma unroll
         for (int k = 0; k < NB; ++k)
@@ -667,34 +627,20 @@ struct TileGroup {
                     if (rin >= jb && rin < jb + BC && col >= j0 + BC) acc[k][r] = (T)0;
                 }
             }
-#if defined(RACE_PRESLEEP)   /* a delay AHEAD of the operand reads, BEHIND the vector instructions that zero accumulator entries */
-        __builtin_amdgcn_s_sleep(RACE_PRESLEEP);
-#endif
         const T* hsp = hs + ((p & 1) * SB) * BC + fk;
         T bf = cs[col * LS + j0 + fk];
         T af[NB > 0 ? NB : 1];
 #pragma unroll
         for (int k = 0; k < NB; ++k) af[k] = hsp[((BR0 + k) * 16 + fcol) * BC];
-#ifdef CIMRGP_RACE_DETECT
-        const T bf_first = bf;
-        T af_first[NB > 0 ? NB : 1];
-#pragma unroll
-        for (int k = 0; k < NB; ++k) af_first[k] = af[k];
-#endif
         if (col < j0 + BC) bf = (T)0;
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const int arow = (BR0 + k) * 16 + fcol;
             if (arow > j0 + fk && arow < j0 + BC) af[k] = (T)0;
         }
-#if defined(RACE_VNOP)      /* wait states between the vector instructions that wrote accumulator entries and the multiplies that read them */
-#pragma unroll
-        for (int k = 0; k < NB; ++k) asm volatile("s_nop %1" : "+v"(acc[k]) : "n"(RACE_VNOP));
-#endif
 #pragma unroll
         for (int k = 0; k < NB; ++k) acc[k] = mfma_k4(af[k], bf, acc[k]);
-#ifndef CIMRGP_GATHER_FIRST
-        // the hand-over right behind the multiplies (the columns leave updated through block p)
+#ifdef CIMRGP_GATHER_LATE     /* tools/lab/race_probe.hip: the hand-over right behind the multiplies (the columns leave updated through block p) */
 #ifdef RACE_NOPS_AFTER       /* idle wait states (16 per s_nop 15) between the multiplies and the LDS writes of their results */
 #pragma unroll
         for (int z = 0; z < RACE_NOPS_AFTER; ++z)
@@ -710,25 +656,9 @@ struct TileGroup {
                     const int grow = (BR0 + k) * 16 + X::crow(lane, r);
                     pc[grow * BC] = (grow >= j0 + BC && grow < g0) ? (T)0 : acc[k][r];
                 }
-#ifndef CIMRGP_RACE_UNSETTLED       /* (tools/lab/race_probe.hip reproduces the round-4 wrong results without this line) */
-            // the gathering lanes read their LAST word back before the wave may arrive at the barrier: only then are
-            // the stores above in the LDS array for the pivot wave's read right behind it (lds_settle, common.hpp)
+#ifndef CIMRGP_RACE_UNSETTLED       /* (the probe reproduces the wrong results without this line) */
             lds_settle(pc + ((BR0 + NB - 1) * 16 + X::crow(lane, 3)) * BC);
 #endif
-        }
-#endif
-#ifdef CIMRGP_RACE_DETECT
-        {
-            // the operands again, hundreds of cycles behind the barrier (block p's hs / cs entries are not rewritten before the next barrier)
-            const volatile T* hv = hsp;
-            const volatile T* cv2 = cs;
-            const T bf2 = cv2[col * LS + j0 + fk];
-            if (__float_as_int((float)bf2) != __float_as_int((float)bf_first)) race_note(1, p, lane, BCOL, (float)bf_first, (float)bf2, BCOL);
-#pragma unroll
-            for (int k = 0; k < NB; ++k) {
-                const T a2 = hv[((BR0 + k) * 16 + fcol) * BC];
-                if (__float_as_int((float)a2) != __float_as_int((float)af_first[k])) race_note(0, p, lane, BR0 + k, (float)af_first[k], (float)a2, BCOL);
-            }
         }
 #endif
     }
@@ -736,7 +666,7 @@ struct TileGroup {
 
 // one tile wave's whole pivot loop (two groups; the second may be empty)
 template <typename T, int NB, int BCOL, int BR0, int NB2 = 0, int BCOL2 = 0, int BR02 = 0>
-static __device__ __forceinline__ void tile_wave_loop(const T* hs, const T* cs, T* pcol, int lane RACE_ARG)
+static __device__ __forceinline__ void tile_wave_loop(const T* hs, const T* cs, T* pcol, int lane)
 {
     TileGroup<T, NB, BCOL, BR0> ga;
     TileGroup<T, NB2, BCOL2, BR02> gb;
@@ -748,8 +678,8 @@ static __device__ __forceinline__ void tile_wave_loop(const T* hs, const T* cs, 
 #if defined(DIAG_EXP) && DIAG_EXP == 1
         continue;
 #endif
-        ga.step(p, hs, cs, pcol, lane RACE_PASS);
-        if (NB2 > 0) gb.step(p, hs, cs, pcol, lane RACE_PASS);
+        ga.step(p, hs, cs, pcol, lane);
+        if (NB2 > 0) gb.step(p, hs, cs, pcol, lane);
     }
 }
 
@@ -764,12 +694,6 @@ static __device__ __forceinline__ void diag_tail_lds(int tw, bool pivot, T* __re
     constexpr int NP = SB / BC;
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = lane;
-#ifdef CIMRGP_RACE_DUMP
-    __shared__ int race_slot_s;
-    if (tid == 0) race_slot_s = (blockIdx.y == 0 && g_race_buf) ? atomicAdd(&g_race_slot, 1) : -1;
-    __syncthreads();
-    const int dslot = race_slot_s;
-#endif
     if (pivot) {
         // ---- pivot wave: the recurrence and nothing else
         T cv[BC], hsr[BC], hsr2[BC];                 // this row's block columns, left operands of the last two blocks
@@ -790,7 +714,7 @@ static __device__ __forceinline__ void diag_tail_lds(int tw, bool pivot, T* __re
         for (int p = 0; p < NP; ++p) {
             if (p == 8) STAMPW(16, DG_TW);
             T nx[BC];
-#ifndef CIMRGP_GATHER_FIRST
+#ifdef CIMRGP_GATHER_LATE
             if (p < 2) {
 #else
             if (p < 3) {
@@ -803,11 +727,6 @@ static __device__ __forceinline__ void diag_tail_lds(int tw, bool pivot, T* __re
 #pragma unroll
                 for (int t = 0; t < BC; ++t) nx[t] = gp[t];
             }
-#ifdef CIMRGP_RACE_DUMP
-            T nx0[BC];
-#pragma unroll
-            for (int t = 0; t < BC; ++t) nx0[t] = nx[t];
-#endif
 #ifdef CIMRGP_RACE_PDUMP
             if (g_race_pbuf != nullptr && blockIdx.y == 0) {
                 float* out = g_race_pbuf + ((((col_base >> 6) & 3) * 16 + p) * 64 + i) * 4;
@@ -815,34 +734,8 @@ static __device__ __forceinline__ void diag_tail_lds(int tw, bool pivot, T* __re
                 for (int t = 0; t < BC; ++t) out[t] = (float)nx[t];
             }
 #endif
-#ifdef CIMRGP_RACE_DETECT
-            T nx_first[BC];
-#pragma unroll
-            for (int t = 0; t < BC; ++t) nx_first[t] = nx[t];
-#endif
 #if !defined(DIAG_EXP) || DIAG_EXP != 2      /* timing-only builds of tools/diag_probe.hip: 1 = tile waves idle, 2 = pivot wave idle */
             pivot_block<T>(p, nx, cv, hsr, hsr2, sm1, sm2, &hs[((p & 1) * SB + i) * BC], cs, i);
-#endif
-#ifdef CIMRGP_RACE_DETECT
-#ifndef CIMRGP_GATHER_FIRST
-            if (p >= 2) {
-#else
-            if (p >= 3) {
-#endif
-                const volatile T* gv = &pcol[((p & 1) * SB + i) * BC];
-#pragma unroll
-                for (int t = 0; t < BC; ++t) {
-                    const T g2 = gv[t];
-                    if (__float_as_int((float)g2) != __float_as_int((float)nx_first[t])) race_note(2, p, i, t, (float)nx_first[t], (float)g2, 0);
-                }
-            }
-#endif
-#ifdef CIMRGP_RACE_DUMP
-            if (dslot >= 0) {
-                float* out = g_race_buf + (size_t)dslot * RD_WORDS + (p * 64 + i) * 8;
-#pragma unroll
-                for (int t = 0; t < BC; ++t) { out[t] = (float)nx0[t]; out[4 + t] = (float)cv[t]; }
-            }
 #endif
             lds_barrier();
             if (p == 8) STAMPW(20, DG_TW);
@@ -852,16 +745,16 @@ static __device__ __forceinline__ void diag_tail_lds(int tw, bool pivot, T* __re
         lds_barrier();
         for (int p = 0; p < NP; ++p) lds_barrier();
     } else if (NTW == 6) {
-        if (tw == 0)      tile_wave_loop<T, 2, 3, 0>(hs, cs, pcol, lane RACE_PASS);
-        else if (tw == 1) tile_wave_loop<T, 2, 3, 2>(hs, cs, pcol, lane RACE_PASS);
-        else if (tw == 2) tile_wave_loop<T, 2, 2, 0>(hs, cs, pcol, lane RACE_PASS);
-        else if (tw == 3) tile_wave_loop<T, 2, 2, 2>(hs, cs, pcol, lane RACE_PASS);
-        else if (tw == 4) tile_wave_loop<T, 4, 1, 0>(hs, cs, pcol, lane RACE_PASS);
-        else              tile_wave_loop<T, 4, 0, 0>(hs, cs, pcol, lane RACE_PASS);
+        if (tw == 0)      tile_wave_loop<T, 2, 3, 0>(hs, cs, pcol, lane);
+        else if (tw == 1) tile_wave_loop<T, 2, 3, 2>(hs, cs, pcol, lane);
+        else if (tw == 2) tile_wave_loop<T, 2, 2, 0>(hs, cs, pcol, lane);
+        else if (tw == 3) tile_wave_loop<T, 2, 2, 2>(hs, cs, pcol, lane);
+        else if (tw == 4) tile_wave_loop<T, 4, 1, 0>(hs, cs, pcol, lane);
+        else              tile_wave_loop<T, 4, 0, 0>(hs, cs, pcol, lane);
     } else {
-        if (tw == 0)      tile_wave_loop<T, 4, 3, 0>(hs, cs, pcol, lane RACE_PASS);
-        else if (tw == 1) tile_wave_loop<T, 4, 2, 0>(hs, cs, pcol, lane RACE_PASS);
-        else              tile_wave_loop<T, 4, 1, 0, 4, 0, 0>(hs, cs, pcol, lane RACE_PASS);
+        if (tw == 0)      tile_wave_loop<T, 4, 3, 0>(hs, cs, pcol, lane);
+        else if (tw == 1) tile_wave_loop<T, 4, 2, 0>(hs, cs, pcol, lane);
+        else              tile_wave_loop<T, 4, 1, 0, 4, 0, 0>(hs, cs, pcol, lane);
     }
     STAMP(3);
     __syncthreads();
@@ -1850,9 +1743,9 @@ void k_rows_step(T* __restrict__ P, int64_t ldp, int M, const T* __restrict__ Lr
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const uint2 an = X::neg(ROWS_SLOT(a, s));
+                const uint2 an = ROWS_SLOT(a, s);          // negated by the multiply itself (Mx<T>::mma_neg)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = X::mma(an, ROWS_SLOT(ring1[c % RS::RING1][j], s), acc[j]);
+                for (int j = 0; j < 4; ++j) acc[j] = X::mma_neg(an, ROWS_SLOT(ring1[c % RS::RING1][j], s), acc[j]);
             }
             if (c + RS::RING1 < RS::NCP) ROWS_P1_LOAD(c + RS::RING1)
         }
@@ -1874,7 +1767,7 @@ void k_rows_step(T* __restrict__ P, int64_t ldp, int M, const T* __restrict__ Lr
             a[1] = *reinterpret_cast<const v4u*>(wbase + c * 128 + 16);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-                acc[j] = X::mma(X::neg(ROWS_SLOT(a, s)), ROWS_SLOT(ring2[pos % RS::RING2], s), acc[j]);
+                acc[j] = X::mma_neg(ROWS_SLOT(a, s), ROWS_SLOT(ring2[pos % RS::RING2], s), acc[j]);
             if (pos + RS::RING2 < RS::P2_TOTAL) ROWS_P2_LOAD(pos + RS::RING2)
         }
 #pragma unroll

@@ -187,6 +187,46 @@ def test_potrf_f32_lookahead_backward_error(dev, n, m):
         assert err < 2e-3, err
 
 
+def test_potrf_f32_beside_a_running_update_is_bit_equal_to_the_undisturbed_run(dev):
+    """Round 5: the situation of the round-4 wrong results, run ONCE.  An FP32 factorisation above
+    the one-queue limit (four-wave chain kernels beside their own FP32 trailing updates) while ANOTHER stream keeps FP32
+    updates of a second matrix running on every compute unit: the factor must equal, bit for bit, the one computed with
+    nothing beside it, and pass the backward-error bar.  The cause was a hand-off through LDS (tools/lab/race_probe.hip:
+    the gathering wave's last ds_write instructions were not in the LDS array when the pivot wave read behind the
+    barrier); a chain workgroup that shares its compute unit with an update workgroup is what exposed it."""
+    n, mu, k = 5632, 6144, 256
+    rng = np.random.default_rng(77)
+    x = np.sort(rng.uniform(-2.0, 2.0, size=(n, 1)), axis=0)
+    ell, sf2, noise = 0.05, 1.0, 0.1
+    xd = dev.to_device(x, torch.float32, "cuda")
+
+    def factor():
+        kbuf = dev.rbf_gram(xd, ell, sf2, noise, lower_only=True)
+        ws, info = dev.potrf(kbuf, n)
+        return kbuf, info
+
+    kref, iref = factor()
+    torch.cuda.synchronize()
+    assert int(iref.item()) == 0
+    k64 = torch.tril(dev.rbf_gram(xd, ell, sf2, noise, lower_only=True)[:n, :n]).double()
+    k64 = k64 + torch.tril(k64, -1).t()
+    cbuf = dev.alloc_matrix(mu, mu, torch.float32, "cuda")
+    abuf = dev.alloc_matrix(mu, k, torch.float32, "cuda")
+    cbuf.zero_(); abuf.zero_()
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(40):                                   # ~40 x 0.3 ms of FP32 tile-kernel workgroups on every unit
+            dev.syrk_lower(cbuf, abuf, mu, k)
+    kgot, igot = factor()
+    torch.cuda.synchronize()
+    assert int(igot.item()) == 0
+    assert torch.equal(torch.tril(kgot[:n, :n]), torch.tril(kref[:n, :n]))
+    l64 = torch.tril(kgot[:n, :n]).double()
+    resid = float(torch.linalg.norm(l64 @ l64.t() - k64) / torch.linalg.norm(k64))
+    assert resid < 64 * np.sqrt(n) * float(np.finfo(np.float32).eps), resid
+
+
 def test_more_caller_streams_than_contexts(dev):
     """Ten caller streams factor matrices above the one-queue limit at the same time: beyond the eight look-ahead
     contexts of a device callers share a context by hash -- and must not share its gate counter (only the context's

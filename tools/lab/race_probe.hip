@@ -1,11 +1,11 @@
 // Diagnostic for the round-4 FP32 wrong-result race of the four-wave chain (HISTORY.md, rounds 4 and 5).
-// Builds the ROUND-3 hand-over (CIMRGP_HANDOVER_LATE: the gather right behind a step's multiplies) and runs
-// one panel chain (k_diag64q, three k_linkq, k_trsm64) beside a running FP32 trailing update on another stream.
-// With CIMRGP_RACE_DUMP every chain kernel also writes, per block of 4 pivots, what the pivot wave READ (its 4
-// columns as gathered) and PUBLISHED, and per gather what the gathering tile wave's accumulators hold one barrier
-// later against what it reads back from the LDS words it wrote: the first record that differs from the undisturbed
-// reference run says where a wrong run went wrong.
-// Not part of the product.  tools/lab/race_probe.sh builds the variants.
+// Built with -DCIMRGP_GATHER_LATE (the round-3 hand-over: the gather right behind a step's multiplies) it runs one
+// panel chain (k_diag64q, three k_linkq, k_trsm64) beside a running FP32 trailing update on another stream and
+// compares every repetition with an undisturbed first one, bit for bit.  With -DCIMRGP_RACE_PDUMP the pivot wave also
+// records, per block of 4 pivots, the 4 columns it READ as gathered: in a wrong run the first differing words are,
+// bit for bit, what the same LDS words held two blocks earlier -- the gathering wave's last store instruction(s) had
+// not been performed when the pivot wave read behind the barrier.  Variants and results: tools/lab/race_probe.sh.
+// Not part of the product.
 #include "../../cimrgp_amd/csrc/potrf.hip"
 #include "../../cimrgp_amd/csrc/gemm_nt.hip"
 #include <cmath>
@@ -32,12 +32,6 @@ int main(int argc, char** argv)
     hipMalloc(&dC, (size_t)mu * ldu * 4); hipMalloc(&dA, (size_t)mu * 256 * 4); hipMalloc(&dinfo, 4);
     hipMemset(dC, 0, (size_t)mu * ldu * 4); hipMemset(dA, 0, (size_t)mu * 256 * 4);
     hipStream_t s1, s2; hipStreamCreateWithFlags(&s1, hipStreamNonBlocking); hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
-#ifdef CIMRGP_RACE_DUMP
-    const int NSLOT = 4;                                   // k_diag64q + three k_linkq
-    float* dbuf; hipMalloc(&dbuf, (size_t)NSLOT * RD_WORDS * 4);
-    hipMemcpyToSymbol(HIP_SYMBOL(g_race_buf), &dbuf, sizeof(dbuf));
-    std::vector<float> dref((size_t)NSLOT * RD_WORDS), dgot((size_t)NSLOT * RD_WORDS);
-#endif
 #ifdef CIMRGP_RACE_PDUMP
     const int PW = 4 * 16 * 64 * 4;
     float* pbuf; hipMalloc(&pbuf, PW * 4);
@@ -47,18 +41,11 @@ int main(int argc, char** argv)
     int mism = 0, shown = 0;
     for (int it = 0; it < reps; ++it) {
         hipMemcpy(dM, hf.data(), hf.size() * 4, hipMemcpyHostToDevice); hipMemset(dinfo, 0, 4);
-#ifdef CIMRGP_RACE_DUMP
-        { int z = 0; hipMemcpyToSymbol(HIP_SYMBOL(g_race_slot), &z, 4); hipMemset(dbuf, 0, (size_t)NSLOT * RD_WORDS * 4); }
-#endif
         hipDeviceSynchronize();
         if (it) gemm_nt_sub<float>(dC, ldu, dA, 256, dA, 256, mu, mu, 256, true, s2);      // the co-runner (not for the reference run)
         panel_chain<float>(dM, nn, lds, dW, dinfo, 0, 256, (float*)nullptr, 0, 0, PotrfBatch(), s1, "probe", false);
         hipDeviceSynchronize();
         for (int r = 0; r < nn; ++r) hipMemcpy(&got[(size_t)r * 256], dM + (size_t)r * lds, 256 * 4, hipMemcpyDeviceToHost);
-#ifdef CIMRGP_RACE_DUMP
-        hipMemcpy(dgot.data(), dbuf, dgot.size() * 4, hipMemcpyDeviceToHost);
-        if (it == 0) dref = dgot;
-#endif
 #ifdef CIMRGP_RACE_PDUMP
         hipMemcpy(pgot.data(), pbuf, PW * 4, hipMemcpyDeviceToHost);
         if (it == 0) pref = pgot;
@@ -102,67 +89,7 @@ int main(int argc, char** argv)
             if (!found) printf("   the pivot wave read the same gathered columns as in the reference run in every block\n");
         }
 #endif
-#ifdef CIMRGP_RACE_DUMP
-        // first differing record, in time order: slot (kernel of the chain), block p, kind
-        bool found = false;
-        for (int sl = 0; sl < NSLOT && !found; ++sl) {
-            const float* a = &dref[(size_t)sl * RD_WORDS];
-            const float* b = &dgot[(size_t)sl * RD_WORDS];
-            for (int p = 0; p < 16 && !found; ++p) {
-                // order inside pivot iteration p: the pivot wave reads block p (gathered in tile step p-2, LATE form), publishes it
-                auto cmp = [&](const char* what, const float* x, const float* y, int per, int off, int cntw) {
-                    int nd = 0;
-                    for (int l = 0; l < 64; ++l) for (int t = 0; t < cntw; ++t)
-                        if (memcmp(&x[l * per + off + t], &y[l * per + off + t], 4)) {
-                            if (nd++ < 10) printf("   slot %d block %d %s: lane %d word %d ref %.9g got %.9g\n", sl, p, what, l, t, x[l * per + off + t], y[l * per + off + t]);
-                        }
-                    if (nd) { printf("   -> slot %d block %d %s: %d words differ\n", sl, p, what, nd); found = true; }
-                    return nd;
-                };
-                if (p >= 2) {
-                    // the gather of block p happened in tile step p-2: true accumulators and LDS read-back
-                    const int q = p - 2;
-                    const float* ga = a + RD_PIV + (size_t)q * 64 * 32;
-                    const float* gb = b + RD_PIV + (size_t)q * 64 * 32;
-                    int n1 = cmp("gather: accumulators one barrier later vs reference", ga, gb, 32, 0, 16);
-                    int n2 = cmp("gather: LDS read-back vs reference", ga, gb, 32, 16, 16);
-                    // within this run: read-back against own accumulators
-                    int nd = 0;
-                    for (int l = 0; l < 64; ++l) for (int t = 0; t < 16; ++t)
-                        if (memcmp(&gb[l * 32 + t], &gb[l * 32 + 16 + t], 4)) {
-                            if (nd++ < 10) printf("   slot %d block %d: lane %d tile %d reg %d: wrote %.9g but the accumulator holds %.9g one barrier later\n", sl, p, l, t / 4, t % 4, gb[l * 32 + 16 + t], gb[l * 32 + t]);
-                        }
-                    if (nd) { printf("   -> slot %d block %d: %d words of the gather differ from the accumulators one barrier later (n1 %d n2 %d)\n", sl, p, nd, n1, n2); found = true; }
-                }
-                cmp("pivot wave READ", a + (size_t)p * 64 * 8, b + (size_t)p * 64 * 8, 8, 0, 4);
-                cmp("pivot wave PUBLISHED", a + (size_t)p * 64 * 8, b + (size_t)p * 64 * 8, 8, 4, 4);
-            }
-        }
-        if (!found) printf("   no dump record differs from the reference\n");
-#endif
     }
-#ifdef CIMRGP_RACE_DETECT
-    {
-        int cnt[4]; static float rec[3][64][6];
-        hipMemcpyFromSymbol(cnt, HIP_SYMBOL(g_race_cnt), sizeof(cnt));
-        hipMemcpyFromSymbol(rec, HIP_SYMBOL(g_race_rec), sizeof(rec));
-        const char* kind[3] = {"tile wave: left operand hs[row][k] read right behind the barrier != read again at the end of the step",
-                               "tile wave: right operand cs[col][j0 + k] first read != second read",
-                               "pivot wave: gathered column pcol[row][t] first read != second read"};
-        for (int k = 0; k < 3; ++k) {
-            printf("DETECT %s: %d events over %d repetitions\n", kind[k], cnt[k], reps);
-            for (int e = 0; e < cnt[k] && e < 64; ++e)
-                printf("   block p = %d lane %d (fcol %d, k-slot %d) index %d first %.9g second %.9g (column block / wave %d)\n", (int)rec[k][e][0], (int)rec[k][e][1],
-                       (int)rec[k][e][1] & 15, (int)rec[k][e][1] >> 4, (int)rec[k][e][2], rec[k][e][3], rec[k][e][4], (int)rec[k][e][5]);
-        }
-    }
-#endif
-    printf("FP32 panel chain (round-3 hand-over%s) beside a running update: %d of %d repetitions differ from the undisturbed first\n",
-#ifdef CIMRGP_RACE_DUMP
-           ", dumps on",
-#else
-           "",
-#endif
-           mism, reps - 1);
+    printf("FP32 panel chain (round-3 hand-over) beside a running update: %d of %d repetitions differ from the undisturbed first\n", mism, reps - 1);
     return 0;
 }
