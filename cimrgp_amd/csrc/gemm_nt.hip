@@ -83,35 +83,60 @@ void k_gemm_nt_sub(T* __restrict__ C, int64_t ldc,
 // round: TCC hit rate 45 %, 500 MB of the 1 GB of operand reads per launch at M = 7936 came from beyond L2.)
 constexpr int PERS_STRIP = 4;
 
+// q / d for 0 <= q < 2^22, 1 <= d: a float quotient with one fix-up either way (scalar code has no integer divide, and
+// the generic sequence is ~30 instructions that all eight waves of a workgroup push through the ONE scalar unit)
+static __device__ __forceinline__ int pers_div(int q, int d)
+{
+    int r = (int)((float)q / (float)d);
+    r -= (r * d > q);
+    r += ((r + 1) * d <= q);
+    return r;
+}
+
+// Closed form, straight-line (round 5: the strip-by-strip search loop of rounds 3-4 was ~350 scalar instructions per
+// tile and wave, and eight waves share one scalar unit: 1800 of a tile's 72 000 clocks, tools/lab/pers_stamps.py).
+// LOWER: full strips hold 16 s + 10 tiles, so strip s starts at tile 8 s^2 + 2 s.
 template <bool LOWER>
 static __device__ __forceinline__ void pers_tile_decode(int q, int tiles_m, int tiles_n, int& ti, int& tj)
 {
     if (LOWER) {
         // strip s holds rows [S s, min(S s + S, tiles_m)); column c of a strip holds its rows >= c
-        int s = 0, base = 0;
-        for (;; ++s) {
-            const int r0 = PERS_STRIP * s;
-            const int h = min(PERS_STRIP, tiles_m - r0);
-            const int cnt = h * r0 + h * (h + 1) / 2;
-            if (q < base + cnt) {
-                const int off = q - base;
-                if (off < h * r0) { tj = off / h; ti = r0 + off - tj * h; return; }
-                int o2 = off - h * r0;              // inside the h x h triangle on the diagonal, column by column
-                int c = 0;
-                while (o2 >= h - c) { o2 -= h - c; ++c; }
-                tj = r0 + c;
-                ti = r0 + c + o2;
-                return;
+        static_assert(PERS_STRIP == 4, "closed form below");
+        const int sfull = tiles_m >> 2;
+        int s, h;
+        if (q < 8 * sfull * sfull + 2 * sfull) {
+            s = (int)((sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.125f);
+            s -= (8 * s * s + 2 * s > q);
+            s += (8 * (s + 1) * (s + 1) + 2 * (s + 1) <= q);
+            h = 4;
+        } else {
+            s = sfull;
+            h = tiles_m - 4 * sfull;
+        }
+        const int r0 = 4 * s;
+        const int off = q - (8 * s * s + 2 * s);
+        if (off < h * r0) {
+            tj = (h == 4) ? (off >> 2) : (h == 2) ? (off >> 1) : (h == 1) ? off : (int)(((unsigned)off * 43691u) >> 17);   // off / 3: off < 3 * 4 * 512
+            ti = r0 + off - tj * h;
+        } else {
+            int o2 = off - h * r0, c = 0;            // inside the h x h triangle on the diagonal, column by column (h - c tiles each)
+            if (o2 >= h) {
+                o2 -= h; c = 1;
+                if (o2 >= h - 1) {
+                    o2 -= h - 1; c = 2;
+                    if (o2 >= h - 2) { o2 -= h - 2; c = 3; }
+                }
             }
-            base += cnt;
+            tj = r0 + c;
+            ti = r0 + c + o2;
         }
     } else {
         const int per_strip = PERS_STRIP * tiles_n;
-        const int s = q / per_strip;
+        const int s = pers_div(q, per_strip);
         const int r0 = PERS_STRIP * s;
         const int h = min(PERS_STRIP, tiles_m - r0);
         const int off = q - s * per_strip;
-        tj = off / h;
+        tj = (h == 4) ? (off >> 2) : (h == 2) ? (off >> 1) : (h == 1) ? off : pers_div(off, 3);
         ti = r0 + off - tj * h;
     }
 }
@@ -164,6 +189,9 @@ static __device__ __forceinline__ int pers_tile_number(int w, int i, int grid, i
 #ifndef PERS_EXP
 #define PERS_EXP 0
 #endif
+#ifndef PERS_SYNC_FLAGS
+#define PERS_SYNC_FLAGS 1
+#endif
 // Round 5: the two barriers of a stage are fences + s_barrier (common.hpp), no longer inline assembly whose "memory"
 // clobber the compiler does not apply to a __shared__ array whose address never escapes (the operand ring here).
 #if PERS_EXP == 1
@@ -176,10 +204,10 @@ static __device__ __forceinline__ int pers_tile_number(int w, int i, int grid, i
 #define PERS_BARRIER_A() lds_barrier()              /* stage kt+1's LDS writes are done: s_waitcnt lgkmcnt(0); s_barrier */
 #define PERS_BARRIER_B() lds_barrier_nowait()       /* every wave has consumed stage kt's fragments: s_barrier alone */
 #endif
-#if PERS_EXP == 20          /* diagnostic build (tools/lab/pers_stamps.py): shader-clock stamps of wave 0 at every stage's first barrier, first 8 tiles of every workgroup */
-__device__ long long g_pers_stamp[256][8 * 16 + 2];
+#ifdef PERS_STAMPS          /* diagnostic build (tools/lab/pers_stamps.py): shader-clock stamps of wave 0 at every stage's first barrier, first 8 tiles of every workgroup */
+__device__ long long g_pers_stamp[256][8 * 16 + 4];
 #define PERS_STAMP(slot_) do { if (tid == 0 && it < 8) g_pers_stamp[wg & 255][slot_] = __builtin_amdgcn_s_memtime(); } while (0)
-#define PERS_STAMP_EXIT() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (tid == 0) g_pers_stamp[wg & 255][129] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PERS_STAMP_EXIT() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (tid == 0) { g_pers_stamp[wg & 255][129] = __builtin_amdgcn_s_memtime(); g_pers_stamp[wg & 255][131] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define PERS_STAMP(slot_) do { } while (0)
 #define PERS_STAMP_EXIT() do { } while (0)
@@ -270,17 +298,41 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
             __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
-#if PERS_EXP == 22      /* experiment: static priority for the second-dispatched half of the waves */
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#ifdef PERS_STAMPS
+    if (tid == 0) { g_pers_stamp[wg & 255][128] = __builtin_amdgcn_s_memtime(); g_pers_stamp[wg & 255][130] = __builtin_amdgcn_s_memrealtime(); }
 #endif
-#if PERS_EXP == 20
-    if (tid == 0) g_pers_stamp[wg & 255][128] = __builtin_amdgcn_s_memtime();
+#if PERS_SYNC_FLAGS
+    // Stage hand-offs by FLAGS in LDS instead of s_barrier (round 5).  A wave posts its stage number in its own word
+    // right behind the LDS accesses the others wait for (the LDS executes a wave's accesses in issue order, so when the
+    // post is visible those accesses have been performed) and polls the eight words where it used to stop at a barrier;
+    // the poll's read is issued one multiply group ahead of its test.  Measured with the stamped builds
+    // (tools/lab/pers_stamps.py): the two barriers of a stage cost ~250 of its ~4530 clocks -- a wave that arrives at
+    // s_barrier LAST finds its SIMD partner already waiting, and the matrix core then idles for the barrier's round trip.
+    __shared__ int flag_a[8], flag_b[8];           // a: my share of the next stage is written; b: my last fragment reads of this stage are issued
+    if (tid < 8) { flag_a[tid] = -1; flag_b[tid] = -1; }
+    int gstage = 0;                                // stages since the launch (wave-uniform)
+    // (relaxed workgroup-scope atomics on the __shared__ words themselves: plain ds_write_b32 / ds_read_b32, no wait of their
+    //  own; the compiler-only fences keep the LDS accesses around them in program order, the LDS keeps them in issue order)
+#define PERS_POST(flag_)  do { __atomic_signal_fence(__ATOMIC_SEQ_CST);                                                  \
+                               __hip_atomic_store(&flag_[wave], gstage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  \
+                               __atomic_signal_fence(__ATOMIC_SEQ_CST); } while (0)
+#define PERS_PEEK(flag_)  __hip_atomic_load(&flag_[lane & 7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define PERS_WAIT(flag_, seen_, g_)                                                                              \
+        do {                                                                                                     \
+            int v_ = (seen_);                                                                                    \
+            while (__builtin_amdgcn_ballot_w64(v_ - (g_) < 0) != 0ull) v_ = PERS_PEEK(flag_);                    \
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);                                                             \
+        } while (0)
 #endif
     int it = 0;                                   // this workgroup's tile counter
     int t = pers_tile_number(wg, it, grid, ntiles);
     if (t < 0) return;
     int ti, tj;
     decode(t, ti, tj);
+    // the NEXT tile's number and coordinates, computed one pass ahead in the shadow of the multiplies (scalar code
+    // between two matrix-core instructions costs nothing; at the top of a pass it stops all eight waves)
+    int t_nx = pers_tile_number(wg, 1, grid, ntiles), ti_nx = ti, tj_nx = tj;
+    if (t_nx >= 0) decode(t_nx, ti_nx, tj_nx);
     bool prev_head = false;                       // the tile being stored during this pass is one the chain waits for
     T* c_cur = C + (int64_t)ti * GT * ldc + (int64_t)tj * GT;
     const T* a_cur = A + (int64_t)ti * GT * lda;
@@ -288,13 +340,8 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
     T* c_prv = c_cur;
     // first-class vectors: arrays of HIP's uint4 struct filled from global memory can stay in scratch
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-#if PERS_EXP == 21      /* experiment: operands requested TWO stages ahead (two register sets) */
-    v4u ra2[2][2], rb2[2][2];
-#define ra ra2[0]
-#define rb rb2[0]
-#else
     v4u ra[2], rb[2];
-#endif
+    const v4u sign4 = {0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u};
     uint2 fa[2][4], fb[2][2];                                // two fragment sets: k-step s+1 is read while s is multiplied
     acc_t acc0[4][2], acc1[4][2];
 
@@ -310,7 +357,9 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
         unsigned char* as_ = smem + (buf_) * 2 * OP_BYTES;                         \
         unsigned char* bs_ = as_ + OP_BYTES;                                       \
         _Pragma("unroll") for (int p = 0; p < 2; ++p) {                            \
-            *reinterpret_cast<v4u*>(as_ + (sr + 64 * p) * LROW + sc * 16) = ra[p]; \
+            /* FP32: the sign of C - A B^T goes into the staged A (4 flips per 16 bytes here against 8 per k-step at */ \
+            /* the fragments); FP64: the multiply negates its operand itself (Mx<T>::mma_neg)                      */ \
+            *reinterpret_cast<v4u*>(as_ + (sr + 64 * p) * LROW + sc * 16) = (sizeof(T) == 4) ? (ra[p] ^ sign4) : ra[p]; \
             *reinterpret_cast<v4u*>(bs_ + (sr + 64 * p) * LROW + sc * 16) = rb[p]; \
         }                                                                          \
     }
@@ -328,7 +377,8 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
     {                                                                              \
         _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                         \
             _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                       \
-                cur_[mi][ni] = X::mma_neg(fa[set_][mi], fb[set_][ni], cur_[mi][ni]); \
+                cur_[mi][ni] = (sizeof(T) == 4) ? X::mma(fa[set_][mi], fb[set_][ni], cur_[mi][ni])            \
+                                                : X::mma_neg(fa[set_][mi], fb[set_][ni], cur_[mi][ni]);       \
         }                                                                          \
     }
 #define PERS_MMA(cur_, set_)  { PERS_MMA_NF(cur_, set_) __builtin_amdgcn_sched_barrier(0); }
@@ -362,30 +412,7 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) acc1[mi][ni] = acc0[mi][ni];
     PERS_SWRITE(0);
-#if PERS_EXP == 21
-#undef ra
-#undef rb
-#define PERS_GLOAD_S(set_, ap_, bp_, kt_)                                          \
-    {                                                                              \
-        _Pragma("unroll") for (int p = 0; p < 2; ++p) {                            \
-            ra2[set_][p] = *reinterpret_cast<const v4u*>((ap_) + (a_off_e[p] + (kt_) * BKE)); \
-            rb2[set_][p] = *reinterpret_cast<const v4u*>((bp_) + (b_off_e[p] + (kt_) * BKE)); \
-        }                                                                          \
-    }
-#define PERS_SWRITE_S(set_, buf_)                                                  \
-    {                                                                              \
-        unsigned char* as_ = smem + (buf_) * 2 * OP_BYTES;                         \
-        unsigned char* bs_ = as_ + OP_BYTES;                                       \
-        _Pragma("unroll") for (int p = 0; p < 2; ++p) {                            \
-            *reinterpret_cast<v4u*>(as_ + (sr + 64 * p) * LROW + sc * 16) = ra2[set_][p]; \
-            *reinterpret_cast<v4u*>(bs_ + (sr + 64 * p) * LROW + sc * 16) = rb2[set_][p]; \
-        }                                                                          \
-    }
-    PERS_GLOAD_S(1, a_cur, b_cur, 1);
-    PERS_GLOAD_S(0, a_cur, b_cur, 2);
-#else
     PERS_GLOAD(a_cur, b_cur, 1);
-#endif
     __syncthreads();
     PERS_FRAGS(0, 0, 0);
 
@@ -412,29 +439,44 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
     /* the stage's events: one (NKT = 16) or two (NKT = 8) */
 #define PERS_EVENT_BLOCK(oth_)                                                                                  \
         { _Pragma("unroll") for (int ev_ = 0; ev_ < EVS; ++ev_) { PERS_EVENT_ONE(oth_, kt * EVS + ev_) } }
-#if PERS_EXP == 21
-#define PERS_STAGE_OPERANDS(kt_)                                                                                \
-            PERS_SWRITE_S(((kt_) + 1) & 1, ((kt_) & 1) ^ 1);                                                    \
-            if ((kt_) + 3 < NKT) PERS_GLOAD_S(((kt_) + 1) & 1, a_cur, b_cur, (kt_) + 3)                         \
-            else                 PERS_GLOAD_S(((kt_) + 1) & 1, a_nxt, b_nxt, (kt_) + 3 - NKT)
-#else
 #define PERS_STAGE_OPERANDS(kt_)                                                                                \
             PERS_SWRITE(((kt_) & 1) ^ 1);           /* stage kt+1, in registers since the previous stage */     \
             if ((kt_) + 2 < NKT) PERS_GLOAD(a_cur, b_cur, (kt_) + 2)    /* stage kt+2 -> registers */            \
             else                 PERS_GLOAD(a_nxt, b_nxt, (kt_) + 2 - NKT)
+#if PERS_SYNC_FLAGS
+#define PERS_SYNC_TOP()      PERS_WAIT(flag_b, seen_b, gstage - 1);
+#define PERS_SYNC_WRITTEN()  PERS_POST(flag_a);
+#define PERS_SYNC_READ()     PERS_POST(flag_b); seen_a = PERS_PEEK(flag_a); __builtin_amdgcn_sched_barrier(0);
+#undef PERS_BARRIER_A
+#undef PERS_BARRIER_B
+#define PERS_BARRIER_A()     PERS_WAIT(flag_a, seen_a, gstage)
+#define PERS_BARRIER_B()     do { } while (0)
+#define PERS_SYNC_PEEK_B()   seen_b = PERS_PEEK(flag_b); __builtin_amdgcn_sched_barrier(0);
+#define PERS_SYNC_NEXT()     ++gstage;
+#else
+#define PERS_SYNC_TOP()
+#define PERS_SYNC_WRITTEN()
+#define PERS_SYNC_READ()
+#define PERS_SYNC_PEEK_B()
+#define PERS_SYNC_NEXT()
 #endif
 #define PERS_PASS(cur_, oth_)                                                                                   \
     {                                                                                                           \
-        const int tn_ = pers_tile_number(wg, it + 1, grid, ntiles);                                             \
+        const int tn_ = t_nx;                                                                                   \
         const bool has_next = tn_ >= 0;                                                                         \
-        int ni_ = ti, nj_ = tj;                                                                                 \
-        if (has_next) decode(tn_, ni_, nj_);                                                                    \
+        const int ni_ = has_next ? ti_nx : ti, nj_ = has_next ? tj_nx : tj;                                     \
         const T* c_nxt = C + (int64_t)ni_ * GT * ldc + (int64_t)nj_ * GT;      /* no next tile: this one */     \
         const __amdgpu_buffer_rsrc_t rs_prv = tile_rsrc(c_prv), rs_nxt = tile_rsrc(c_nxt);                      \
         const T* a_nxt = A + (int64_t)ni_ * GT * lda;                                                           \
         const T* b_nxt = B + (int64_t)nj_ * GT * ldb;                                                           \
         _Pragma("unroll") for (int kt = 0; kt < NKT; ++kt) {                                                    \
+            if (kt == NKT / 2) {                     /* the tile after the next one: number and coordinates */   \
+                t_nx = pers_tile_number(wg, it + 2, grid, ntiles);                                              \
+                if (t_nx >= 0) decode(t_nx, ti_nx, tj_nx);                                                      \
+            }                                                                                                   \
+            PERS_SYNC_TOP()                          /* flags: everyone's reads of the buffer written below are issued */ \
             PERS_STAGE_OPERANDS(kt)                                                                             \
+            PERS_SYNC_WRITTEN()                      /* flags: my share of stage kt+1 is behind me */            \
             if (PERS_EXP != 7 && PERS_EXP != 8) PERS_EVENT_BLOCK(oth_)                                          \
             /* k-step s+1's fragments are requested before k-step s is multiplied (the scheduler is fenced */  \
             /* so that it cannot fold the pairs back into read -> wait -> multiply)                        */  \
@@ -445,13 +487,16 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
             if (PERS_EXP == 7) { PERS_EVENT_BLOCK(oth_) PERS_MMA_NF(cur_, 1); PERS_INTERLEAVE(); }                  \
             else PERS_MMA(cur_, 1);                                                                             \
             PERS_FRAGS(1, kt & 1, 3);                                                                           \
+            PERS_SYNC_READ()                         /* flags: my last reads of stage kt are issued; peek at the others' writes */ \
             PERS_MMA(cur_, 0);                                                                                  \
             PERS_BARRIER_A();                                                    /* stage kt+1 is in LDS */     \
             PERS_STAMP(it * 16 + kt);                                                                                   \
             PERS_FRAGS(0, (kt & 1) ^ 1, 0);         /* first fragments of stage kt+1 */                         \
+            PERS_SYNC_PEEK_B()                       /* flags: a look at the others' last reads, tested at the top of the next stage */ \
             if (PERS_EXP == 8) { PERS_EVENT_BLOCK(oth_) PERS_MMA_NF(cur_, 1); PERS_INTERLEAVE(); }                  \
             else PERS_MMA(cur_, 1);                                                                             \
             PERS_BARRIER_B();                        /* everyone has read stage kt: its buffer may be rewritten */ \
+            PERS_SYNC_NEXT()                                                                                    \
         }                                                                                                       \
         if (prev_head) signal_stored();             /* the previous tile's last store went out in this pass */  \
         prev_head = (t < heads);                                                                                \
@@ -470,12 +515,20 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
         c_cur = const_cast<T*>(c_nxt); a_cur = a_nxt; b_cur = b_nxt;                                            \
     }
 
+#if PERS_SYNC_FLAGS
+    int seen_a = -1, seen_b = -1;                  // the flags as last peeked at (re-read in the wait if not there yet)
+#endif
     for (;;) {
         PERS_PASS(acc0, acc1)
         PERS_PASS(acc1, acc0)
     }
 #undef PERS_PASS
 #undef PERS_STAGE_OPERANDS
+#undef PERS_SYNC_TOP
+#undef PERS_SYNC_WRITTEN
+#undef PERS_SYNC_READ
+#undef PERS_SYNC_PEEK_B
+#undef PERS_SYNC_NEXT
 #undef PERS_EVENT_BLOCK
 #undef PERS_EVENT_ONE
 #undef PERS_INTERLEAVE
@@ -649,10 +702,18 @@ int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t 
             CIMRGP_REQUIRE(!bt.head_first || heads > 0, fn, "a head-first update needs a lower update of at least 3 x 3 tiles");
             const int64_t tiles = (lower ? tm * (tm + 1) / 2 : tm * tn) - (heads ? 1 : 0);
             const int cus = (want < 256 ? want : 256) & ~7;     // one workgroup per compute unit (gfx950: 256), 8 XCDs
-            const int64_t rounds = (tiles + cus - 1) / cus;
+            // A launch lasts a whole number of ROUNDS of tiles (one 128 x 128 tile per workgroup and round), so a few
+            // more workgroups can save a whole round: 1829 tiles take 9 rounds on 224 units and 8 on 232 (-11 %).  With
+            // knobs().pers_flex_cus > 0 the caller's share may be exceeded by that many units when it removes a round.
+            // Round 5 measured it inside the factorisation and left it OFF: what the update gains the panel chain loses.
+            int cus_max = cus + (knobs().pers_flex_cus & ~7);
+            if (cus_max > 256) cus_max = 256;
+            int64_t rounds = (tiles + cus - 1) / cus;
+            int use = cus;
+            if (rounds >= knobs().pers_flex_min_rounds && (tiles + cus_max - 1) / cus_max < rounds) { rounds = (tiles + cus_max - 1) / cus_max; use = cus_max; }
             int64_t g8 = (tiles + rounds - 1) / rounds;         // every workgroup busy in (nearly) every round ...
             g8 = (g8 + 7) / 8 * 8;                              // ... and the same number of them on every XCD
-            if (g8 > cus) g8 = cus;
+            if (g8 > use) g8 = use;
             const dim3 grid((unsigned)g8);
 #define CIMRGP_PERS_LAUNCH(LOW_) \
             hipLaunchKernelGGL((k_gemm_nt_pers<T, LOW_, pers_nkt>), grid, dim3(PERS_THREADS), 0, st, c, ldc, a, lda, b, ldb, (int)tm, (int)tn, (int)tiles, heads, bt.flag)
@@ -672,7 +733,7 @@ int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t 
     return gemm_launch<T, 4>(c, ldc, a, lda, b, ldb, m, n, k, lower, st, bt);
 }
 
-#if PERS_EXP == 20
+#ifdef PERS_STAMPS
 extern "C" int cimrgp_debug_pers_stamps(long long* out_host)
 {
     return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_pers_stamp), sizeof(g_pers_stamp)) == hipSuccess ? 0 : -1;

@@ -1,5 +1,5 @@
 """Where a tile pass of the persistent update spends its time: shader-clock stamps of wave 0 at the first barrier of every
-K stage (PERS_EXP=20 build: bash tools/lab/exp_variants.sh build20), first 8 tiles of every workgroup, one launch.
+K stage (-DPERS_STAMPS build: bash tools/lab/exp_variants.sh build20), first 8 tiles of every workgroup, one launch.
    CIMRGP_LIB_PATH=cimrgp_amd/libcimrgp_tuning_e20.so python tools/lab/pers_stamps.py [m]"""
 import ctypes, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -18,13 +18,14 @@ for _ in range(3):
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); dev.syrk_lower(c, a, m, k); e1.record(); torch.cuda.synchronize()
-buf = (ctypes.c_longlong * (256 * 130))()
+buf = (ctypes.c_longlong * (256 * 132))()
 lib.cimrgp_debug_pers_stamps.restype = ctypes.c_int
 assert lib.cimrgp_debug_pers_stamps(buf) == 0
-raw = np.frombuffer(buf, dtype=np.int64).reshape(256, 130)
+raw = np.frombuffer(buf, dtype=np.int64).reshape(256, 132)
 full = raw[:, 127] != 0                              # workgroups that ran at least 8 tiles
 entry_to_first = raw[full, 0] - raw[full, 128]       # kernel entry -> first stage's barrier (C tile + first operands)
 lifetime = raw[full, 129] - raw[full, 128]
+clock_ghz = np.median(lifetime / np.maximum(1, raw[full, 131] - raw[full, 130])) * 0.1      # s_memrealtime ticks at 100 MHz
 st = raw[full, :128].reshape(-1, 8, 16)
 d = np.diff(st.reshape(-1, 128), axis=1)            # clocks between consecutive stage barriers
 d = d[:, :127]
@@ -35,5 +36,5 @@ print(json.dumps(dict(m=m, launch_us=round(e0.elapsed_time(e1) * 1e3, 1), ideal_
                       frac_over_1p25x=float((d > 1.25 * ideal).mean()), frac_over_2x=float((d > 2 * ideal).mean()),
                       per_stage_position_median=[float(v) for v in np.median(np.diff(st, axis=2).reshape(-1, 15), axis=0)],
                       tile_boundary_median=float(np.median(st[:, 1:, 0] - st[:, :-1, 15])),
-                      workgroups_with_8_tiles=int(full.sum()), entry_to_first_barrier_median=float(np.median(entry_to_first)), entry_to_first_barrier_max=float(entry_to_first.max()), lifetime_median=float(np.median(lifetime)), lifetime_max=float(lifetime.max()),
+                      workgroups_with_8_tiles=int(full.sum()), entry_to_first_barrier_median=float(np.median(entry_to_first)), entry_to_first_barrier_max=float(entry_to_first.max()), lifetime_median=float(np.median(lifetime)), in_kernel_clock_ghz=float(clock_ghz), lifetime_max=float(lifetime.max()),
                       pass_clocks_median=float(np.median(st[:, 1:, 0] - st[:, :-1, 0])))))
