@@ -182,6 +182,7 @@ struct Knobs {
     int tail_far_cus = 160;                // CIMRGP_TAIL_FAR_CUS: compute units of FAR(prev) on the second queue of the fused tail (0: always riders)
     int64_t tail_far_min_rows = 2048;      // CIMRGP_TAIL_FAR_MIN: ... while at least this many rows remain beyond the next panel
     int chain_cus = 32;                    // CIMRGP_CHAIN_CUS: compute units the bulk update leaves to the panel chain (look-ahead phase)
+    int head_direct_max_rounds = 0;        // CIMRGP_HEAD_DIRECT: a head-first persistent update of at most this many rounds stores its head tiles at the end of their own pass (0: always streamed under the next pass)
     int pers_flex_cus = 0;                 // CIMRGP_PERS_FLEX: a persistent update may take up to this many units beyond its share when that saves a whole round of tiles ...
     int pers_flex_min_rounds = 7;          // CIMRGP_PERS_FLEX_MIN: ... of a launch of at least this many rounds.  OFF: measured in round 5 (profiles/r05_flex_scan.txt): the updates
                                            // get 4-8 % shorter (5 of the 83 rounds of a look-ahead phase at n = 8192 go), the step 2-3 % LONGER -- the panel chain needs its 32 units

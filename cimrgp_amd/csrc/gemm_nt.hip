@@ -218,6 +218,11 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const void* p
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
 }
+// the same with NO extent: every access through it is out of range -- stores are dropped, loads return zero
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc_null(const void* p)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0, 0x00020000);
+}
 typedef unsigned int cbuf_u2 __attribute__((ext_vector_type(2)));
 template <typename T> static __device__ __forceinline__ T cbuf_load(__amdgpu_buffer_rsrc_t r, int voff, int soff);
 template <> __device__ __forceinline__ double cbuf_load<double>(__amdgpu_buffer_rsrc_t r, int voff, int soff)
@@ -249,7 +254,8 @@ constexpr int PERS_STAGES = 16;
 template <typename T, bool LOWER, int NKT>
 __global__ __launch_bounds__(PERS_THREADS)
 void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int64_t lda,
-                    const T* __restrict__ B, int64_t ldb, int tiles_m, int tiles_n, int ntiles, int heads, int* __restrict__ flag)
+                    const T* __restrict__ B, int64_t ldb, int tiles_m, int tiles_n, int ntiles, int heads, int* __restrict__ flag,
+                    int head_direct)
 {
     static_assert(NKT == 16 || NKT == 8, "sixteen C events per tile: one or two per K stage");
     constexpr int EVS = 16 / NKT;                            // C events per stage
@@ -334,6 +340,7 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
     int t_nx = pers_tile_number(wg, 1, grid, ntiles), ti_nx = ti, tj_nx = tj;
     if (t_nx >= 0) decode(t_nx, ti_nx, tj_nx);
     bool prev_head = false;                       // the tile being stored during this pass is one the chain waits for
+    bool prv_stored = false;                      // ... or was stored directly already (head_direct)
     T* c_cur = C + (int64_t)ti * GT * ldc + (int64_t)tj * GT;
     const T* a_cur = A + (int64_t)ti * GT * lda;
     const T* b_cur = B + (int64_t)tj * GT * ldb;
@@ -466,7 +473,10 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
         const bool has_next = tn_ >= 0;                                                                         \
         const int ni_ = has_next ? ti_nx : ti, nj_ = has_next ? tj_nx : tj;                                     \
         const T* c_nxt = C + (int64_t)ni_ * GT * ldc + (int64_t)nj_ * GT;      /* no next tile: this one */     \
-        const __amdgpu_buffer_rsrc_t rs_prv = tile_rsrc(c_prv), rs_nxt = tile_rsrc(c_nxt);                      \
+        /* a head tile stored directly at the end of its own pass (head_direct) must NOT be stored again by this  */ \
+        /* pass's events -- the panel chain may be rewriting it already: its descriptor has no extent, the stores drop */ \
+        const __amdgpu_buffer_rsrc_t rs_prv = prv_stored ? tile_rsrc_null(c_prv) : tile_rsrc(c_prv);            \
+        const __amdgpu_buffer_rsrc_t rs_nxt = tile_rsrc(c_nxt);                                                 \
         const T* a_nxt = A + (int64_t)ni_ * GT * lda;                                                           \
         const T* b_nxt = B + (int64_t)nj_ * GT * ldb;                                                           \
         _Pragma("unroll") for (int kt = 0; kt < NKT; ++kt) {                                                    \
@@ -510,6 +520,18 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
             if (prev_head) signal_stored();                                                                     \
             PERS_STAMP_EXIT();                                                                                  \
             return;                                                                                             \
+        }                                                                                                       \
+        prv_stored = false;                                                                                     \
+        if (head_direct && prev_head) {                                                                         \
+            /* the chain waits for this tile: out with it now instead of under the next pass (its round trip is   */ \
+            /* not hidden: only launches whose chain is the longer path ask for this, gemm_nt_sub)                */ \
+            _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                    \
+                _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r)                                               \
+                        (c_cur + ((int64_t)(mi * 16 + RS * r) * ldc + ni * 16))[coff] = cur_[mi][ni][r];        \
+            signal_stored();                                                                                    \
+            prev_head = false;                                                                                  \
+            prv_stored = true;                                                                                  \
         }                                                                                                       \
         t = tn_; ti = ni_; tj = nj_; ++it;                                                                      \
         c_cur = const_cast<T*>(c_nxt); a_cur = a_nxt; b_cur = b_nxt;                                            \
@@ -715,8 +737,11 @@ int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t 
             g8 = (g8 + 7) / 8 * 8;                              // ... and the same number of them on every XCD
             if (g8 > use) g8 = use;
             const dim3 grid((unsigned)g8);
+            // head tiles straight out at the end of their own pass when the launch is short enough for the panel chain --
+            // which waits for them -- to be the longer path of the panel (knobs().head_direct_max_rounds)
+            const int head_direct = (heads > 0 && rounds <= knobs().head_direct_max_rounds) ? 1 : 0;
 #define CIMRGP_PERS_LAUNCH(LOW_) \
-            hipLaunchKernelGGL((k_gemm_nt_pers<T, LOW_, pers_nkt>), grid, dim3(PERS_THREADS), 0, st, c, ldc, a, lda, b, ldb, (int)tm, (int)tn, (int)tiles, heads, bt.flag)
+            hipLaunchKernelGGL((k_gemm_nt_pers<T, LOW_, pers_nkt>), grid, dim3(PERS_THREADS), 0, st, c, ldc, a, lda, b, ldb, (int)tm, (int)tn, (int)tiles, heads, bt.flag, head_direct)
             if (lower) CIMRGP_PERS_LAUNCH(true); else CIMRGP_PERS_LAUNCH(false);
 #undef CIMRGP_PERS_LAUNCH
             CIMRGP_LAUNCH_CHECK(fn);

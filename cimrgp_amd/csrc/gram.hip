@@ -108,6 +108,81 @@ void k_rbf_gram(const T* __restrict__ xa, int na, const T* __restrict__ xb, int 
     gram_tile<T, SYMM, D>(xa, na, xb, nb, d, neg_half_inv_l2, sf2, diag_add, K, ld, tiles_n, lower_only);
 }
 
+// The lower triangle of a symmetric Gram matrix in 64 x 128 tiles (round 5): a tile row is 128 columns = 1 KB in FP64, so
+// every store instruction of a wave writes ONE whole 1-KB run of one matrix row (FP32: two 512-byte runs); tile rows 2p
+// and 2p+1 both need p + 1 tiles, so pair p starts at tile p (p + 1).  In the tile that holds the diagonal, lanes whose
+// columns lie right of the tile's last row have nothing below the diagonal and skip.
+constexpr int GWIDE = 128;
+template <typename T, int D>
+__global__ __launch_bounds__(256)
+void k_rbf_gram_lower_wide(const T* __restrict__ x, int n, int d, T neg_half_inv_l2, T sf2, T diag_add, T* __restrict__ K, int64_t ld)
+{
+    __shared__ T sa[GTILE * MAXD];
+    __shared__ T sb[GWIDE * MAXD];
+    const int id = blockIdx.x;
+    int p = (int)((sqrtf(4.0f * (float)id + 1.0f) - 1.0f) * 0.5f);
+    while (p * (p + 1) > id) --p;
+    while ((p + 1) * (p + 2) <= id) ++p;
+    const int rem = id - p * (p + 1);
+    const int odd = rem >= p + 1;
+    const int ti = 2 * p + odd, tj = rem - odd * (p + 1);
+    const int row0 = ti * GTILE, col0 = tj * GWIDE;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < GWIDE * MAXD; e += 256) {
+        const int r = e / MAXD, k = e - r * MAXD;
+        if (r < GTILE) sa[e] = (k < d && row0 + r < n) ? x[(int64_t)(row0 + r) * d + k] : (T)0;
+        sb[e] = (k < d && col0 + r < n) ? x[(int64_t)(col0 + r) * d + k] : (T)0;
+    }
+    __syncthreads();
+    constexpr int EPL = 16 / (int)sizeof(T);    // elements per lane and row
+    constexpr int LPR = GWIDE / EPL;            // lanes per tile row: 64 (FP64) / 32 (FP32)
+    constexpr int RPI = 64 / LPR;               // rows per wave and store instruction
+    constexpr int NIT = GTILE / (4 * RPI);
+    const int lane = tid & 63, wave = tid >> 6;
+    const int cx = (lane % LPR) * EPL;
+    const int ry = lane / LPR;
+    const int gc = col0 + cx;
+    if (gc > row0 + GTILE - 1) return;          // (behind the only barrier) all of this lane's columns are above the diagonal in every row of the tile
+    constexpr int DD = D ? D : MAXD;
+    T xc[EPL][DD];
+#pragma unroll
+    for (int b = 0; b < EPL; ++b)
+#pragma unroll
+        for (int k = 0; k < DD; ++k) xc[b][k] = sb[(cx + b) * MAXD + k];
+#pragma unroll
+    for (int a = 0; a < NIT; ++a) {
+        const int r = (a * 4 + wave) * RPI + ry;
+        const int gr = row0 + r;
+        if (gr >= n) continue;
+        T out[EPL];
+#pragma unroll
+        for (int b = 0; b < EPL; ++b) {
+            T d2 = (T)0;
+#pragma unroll
+            for (int k = 0; k < DD; ++k) {
+                if (D || k < d) {
+                    const T df = sa[r * MAXD + k] - xc[b][k];
+                    d2 += df * df;
+                }
+            }
+            T v = sf2 * exp(d2 * neg_half_inv_l2);
+            if (gr == gc + b) v += diag_add;
+            out[b] = v;
+        }
+        T* dst = K + (int64_t)gr * ld + gc;
+        if (gc + EPL - 1 < n && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) {
+            typedef double d2v __attribute__((ext_vector_type(2)));
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            if (sizeof(T) == 8) { d2v v = {(double)out[0], (double)out[1]}; __builtin_nontemporal_store(v, reinterpret_cast<d2v*>(dst)); }
+            else { f4v v = {(float)out[0], (float)out[1], (float)out[EPL - 2], (float)out[EPL - 1]}; __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(dst)); }
+        } else {
+#pragma unroll
+            for (int b = 0; b < EPL; ++b)
+                if (gc + b < n) dst[b] = out[b];
+        }
+    }
+}
+
 // The blocks of one layer in one launch (blockIdx.y = block): block b takes its `na` rows of inputs at
 // row a_starts[b] of xa and its `nb` columns at row b_starts[b] of xb (regions are contiguous ranges of
 // the layer's arrays, Inputs.py:57-60), writes matrix b of the arena (stride kstride) and, on the
@@ -196,7 +271,18 @@ int rbf_gram_run(const T* xa, int64_t na, const T* xb, int64_t nb, int d, double
 #define CIMRGP_GRAM_LAUNCH(SYMM_, D_, tiles_, diag_, lo_)                                   \
     hipLaunchKernelGGL((k_rbf_gram<T, SYMM_, D_>), dim3((unsigned)(tiles_)), dim3(256), 0, st, \
                        xa, (int)na, xb, (int)nb, d, c, (T)sf2, (T)(diag_), k, ld, (int)tn, (lo_))
-    if (symm) {
+    if (symm && lower_only && na == nb && xa == xb) {
+        // the lower triangle in 64 x 128 tiles: pairs of tile rows, P (P + 1) tiles in the full pairs (+ P + 1 for an odd last row)
+        const int64_t pairs = tm / 2;
+        const int64_t tiles = pairs * (pairs + 1) + ((tm & 1) ? pairs + 1 : 0);
+        CIMRGP_REQUIRE(tiles < (1ll << 31), fn, "grid too large");
+#define CIMRGP_GRAMW_LAUNCH(D_) hipLaunchKernelGGL((k_rbf_gram_lower_wide<T, D_>), dim3((unsigned)tiles), dim3(256), 0, st, \
+                                                   xa, (int)na, d, c, (T)sf2, (T)diag_add, k, ld)
+        if (d == 1)      CIMRGP_GRAMW_LAUNCH(1);
+        else if (d == 2) CIMRGP_GRAMW_LAUNCH(2);
+        else             CIMRGP_GRAMW_LAUNCH(0);
+#undef CIMRGP_GRAMW_LAUNCH
+    } else if (symm) {
         const int64_t tiles = lower_only ? tm * (tm + 1) / 2 : tm * tn;
         CIMRGP_REQUIRE(tiles < (1ll << 31), fn, "grid too large");
         const int lo = lower_only ? 1 : 0;
