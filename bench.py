@@ -38,7 +38,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32-input MFMA peak
 import workloads
 
 EVENT_EVERY = 4          # timed steps whose trailing-update launches are bracketed by events (main)
-PMC_PROFILE = "r04_pmc_bench_n8192.json"
+PMC_PROFILE = "r05_pmc_bench_n8192.json"
 
 
 def _sources_sha():
