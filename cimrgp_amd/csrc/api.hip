@@ -43,6 +43,7 @@ const Knobs& knobs()
         v.gemm_pers_f32 = (int)num("CIMRGP_GEMM_PERS_F32", v.gemm_pers_f32);
         v.pers_min_tiles = (int)num("CIMRGP_PERS_MIN_TILES", v.pers_min_tiles);
         v.chain_cus = (int)num("CIMRGP_CHAIN_CUS", v.chain_cus);
+        v.pers_max_chunks = (int)num("CIMRGP_PERS_CHUNKS", v.pers_max_chunks);
         v.head_direct_max_rounds = (int)num("CIMRGP_HEAD_DIRECT", v.head_direct_max_rounds);
         v.pers_flex_cus = (int)num("CIMRGP_PERS_FLEX", v.pers_flex_cus);
         v.pers_flex_min_rounds = (int)num("CIMRGP_PERS_FLEX_MIN", v.pers_flex_min_rounds);

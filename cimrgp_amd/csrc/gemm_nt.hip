@@ -251,11 +251,13 @@ constexpr int PERS_STAGES = 16;
 // NKT = K stages of 128 bytes per pass: 16 for K = 256 doubles (or 512 floats), 8 for K = 256 floats (round 4: the
 // FP32 form of one panel -- a stage is the same 128 bytes and the same matrix-core time in both precisions, so an
 // FP32 pass is half as long and carries the tile's sixteen C events two per stage).
-template <typename T, bool LOWER, int NKT>
+// MULTI: K = nkc chunks of NKT stages (a runtime loop around the unrolled stages); false: one chunk, no loop -- the
+// loop costs the one-panel form 1-2 % (profiles/r05_chunk_ab.txt), so the K = 256 launches keep the form without it.
+template <typename T, bool LOWER, int NKT, bool MULTI = false>
 __global__ __launch_bounds__(PERS_THREADS)
 void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int64_t lda,
                     const T* __restrict__ B, int64_t ldb, int tiles_m, int tiles_n, int ntiles, int heads, int* __restrict__ flag,
-                    int head_direct)
+                    int head_direct, int nkc)
 {
     static_assert(NKT == 16 || NKT == 8, "sixteen C events per tile: one or two per K stage");
     constexpr int EVS = 16 / NKT;                            // C events per stage
@@ -448,8 +450,8 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
         { _Pragma("unroll") for (int ev_ = 0; ev_ < EVS; ++ev_) { PERS_EVENT_ONE(oth_, kt * EVS + ev_) } }
 #define PERS_STAGE_OPERANDS(kt_)                                                                                \
             PERS_SWRITE(((kt_) & 1) ^ 1);           /* stage kt+1, in registers since the previous stage */     \
-            if ((kt_) + 2 < NKT) PERS_GLOAD(a_cur, b_cur, (kt_) + 2)    /* stage kt+2 -> registers */            \
-            else                 PERS_GLOAD(a_nxt, b_nxt, (kt_) + 2 - NKT)
+            if ((kt_) + 2 < NKT) PERS_GLOAD(a_chk, b_chk, (kt_) + 2)    /* stage kt+2 -> registers */            \
+            else                 PERS_GLOAD(a_adv, b_adv, (kt_) + 2 - NKT)   /* ... of the next chunk of K, or of the next tile */
 #if PERS_SYNC_FLAGS
 #define PERS_SYNC_TOP()      PERS_WAIT(flag_b, seen_b, gstage - 1);
 #define PERS_SYNC_WRITTEN()  PERS_POST(flag_a);
@@ -473,14 +475,24 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
         const bool has_next = tn_ >= 0;                                                                         \
         const int ni_ = has_next ? ti_nx : ti, nj_ = has_next ? tj_nx : tj;                                     \
         const T* c_nxt = C + (int64_t)ni_ * GT * ldc + (int64_t)nj_ * GT;      /* no next tile: this one */     \
-        /* a head tile stored directly at the end of its own pass (head_direct) must NOT be stored again by this  */ \
-        /* pass's events -- the panel chain may be rewriting it already: its descriptor has no extent, the stores drop */ \
-        const __amdgpu_buffer_rsrc_t rs_prv = prv_stored ? tile_rsrc_null(c_prv) : tile_rsrc(c_prv);            \
         const __amdgpu_buffer_rsrc_t rs_nxt = tile_rsrc(c_nxt);                                                 \
         const T* a_nxt = A + (int64_t)ni_ * GT * lda;                                                           \
         const T* b_nxt = B + (int64_t)nj_ * GT * ldb;                                                           \
+        /* K = nkc chunks of NKT stages (round 5: far updates of two or three panels at once, n > 8192): the same   */ \
+        /* 16-stage body once per chunk, the accumulators carried on.  The C stream belongs to the FIRST chunk:    */ \
+        /* later chunks address the previous tile through a descriptor without extent (their stores drop) and load */ \
+        /* the next tile's values again (the same values into the same registers).                                 */ \
+        for (int kc = 0; kc < (MULTI ? nkc : 1); ++kc) {                                                        \
+        const bool lastc = !MULTI || (kc + 1 == nkc);                                                           \
+        /* a head tile stored directly at the end of its own pass (head_direct) must NOT be stored again by this  */ \
+        /* pass's events -- the panel chain may be rewriting it already: no extent, the stores drop              */ \
+        const __amdgpu_buffer_rsrc_t rs_prv = (prv_stored || kc > 0) ? tile_rsrc_null(c_prv) : tile_rsrc(c_prv); \
+        const T* a_chk = a_cur + kc * (NKT * BKE);                                                              \
+        const T* b_chk = b_cur + kc * (NKT * BKE);                                                              \
+        const T* a_adv = lastc ? a_nxt : a_chk + NKT * BKE;                                                     \
+        const T* b_adv = lastc ? b_nxt : b_chk + NKT * BKE;                                                     \
         _Pragma("unroll") for (int kt = 0; kt < NKT; ++kt) {                                                    \
-            if (kt == NKT / 2) {                     /* the tile after the next one: number and coordinates */   \
+            if (kt == NKT / 2 && lastc) {            /* the tile after the next one: number and coordinates */   \
                 t_nx = pers_tile_number(wg, it + 2, grid, ntiles);                                              \
                 if (t_nx >= 0) decode(t_nx, ti_nx, tj_nx);                                                      \
             }                                                                                                   \
@@ -508,6 +520,7 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
             PERS_BARRIER_B();                        /* everyone has read stage kt: its buffer may be rewritten */ \
             PERS_SYNC_NEXT()                                                                                    \
         }                                                                                                       \
+        }                                           /* chunks of K */                                           \
         if (prev_head) signal_stored();             /* the previous tile's last store went out in this pass */  \
         prev_head = (t < heads);                                                                                \
         c_prv = c_cur;                                                                                          \
@@ -715,7 +728,9 @@ int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t 
         // (knobs().gemm_pers_f32): stand-alone it equals the tile kernel (0.52-0.58 of the FP32 peak both), inside the
         // factorisation it is slower (3.85 against 3.64 ms at n = 8192): HISTORY.md, round 4.
         constexpr int pers_nkt = (sizeof(T) == 8) ? PERS_STAGES : PERS_STAGES / 2;
-        if (want >= 8 && (sizeof(T) == 8 || knobs().gemm_pers_f32) && nkt == pers_nkt && bt.count == 1 && !bt.skip_first && m % 128 == 0 && n % 128 == 0 &&
+        const int nkc = (nkt > 0 && nkt % pers_nkt == 0) ? nkt / pers_nkt : 0;       // chunks of one panel's K (256 columns)
+        if (want >= 8 && (sizeof(T) == 8 || knobs().gemm_pers_f32) && nkc >= 1 && nkc <= knobs().pers_max_chunks && (nkc == 1 || !bt.head_first) &&
+            bt.count == 1 && !bt.skip_first && m % 128 == 0 && n % 128 == 0 &&
             ldc < (1ll << 20) && lda < (1ll << 23) && ldb < (1ll << 23) && (t128 >= knobs().pers_min_tiles || bt.head_first || bt.pers_force)) {
             // (ldc: 128 rows of C stay below 2^31 bytes -- the C stream addresses a tile through a raw buffer with 32-bit offsets)
             const int64_t tm = m / 128, tn = n / 128;
@@ -740,9 +755,10 @@ int gemm_nt_sub(T* c, int64_t ldc, const T* a, int64_t lda, const T* b, int64_t 
             // head tiles straight out at the end of their own pass when the launch is short enough for the panel chain --
             // which waits for them -- to be the longer path of the panel (knobs().head_direct_max_rounds)
             const int head_direct = (heads > 0 && rounds <= knobs().head_direct_max_rounds) ? 1 : 0;
-#define CIMRGP_PERS_LAUNCH(LOW_) \
-            hipLaunchKernelGGL((k_gemm_nt_pers<T, LOW_, pers_nkt>), grid, dim3(PERS_THREADS), 0, st, c, ldc, a, lda, b, ldb, (int)tm, (int)tn, (int)tiles, heads, bt.flag, head_direct)
-            if (lower) CIMRGP_PERS_LAUNCH(true); else CIMRGP_PERS_LAUNCH(false);
+#define CIMRGP_PERS_LAUNCH(LOW_, MULTI_) \
+            hipLaunchKernelGGL((k_gemm_nt_pers<T, LOW_, pers_nkt, MULTI_>), grid, dim3(PERS_THREADS), 0, st, c, ldc, a, lda, b, ldb, (int)tm, (int)tn, (int)tiles, heads, bt.flag, head_direct, nkc)
+            if (lower) { if (nkc > 1) CIMRGP_PERS_LAUNCH(true, true); else CIMRGP_PERS_LAUNCH(true, false); }
+            else       { if (nkc > 1) CIMRGP_PERS_LAUNCH(false, true); else CIMRGP_PERS_LAUNCH(false, false); }
 #undef CIMRGP_PERS_LAUNCH
             CIMRGP_LAUNCH_CHECK(fn);
             return 0;
