@@ -18,9 +18,12 @@ def family(name):
     m = re.search(r"k_gemm_nt_sub<(\w+), (true|false), (\d)>", name)
     if m:
         return "k_gemm_nt_sub<%s,%s,%s-tile>" % (m.group(1), "lower" if m.group(2) == "true" else "rect", 32 * int(m.group(3)))
-    m = re.search(r"k_gemm_nt_pers<(\w+), (true|false)(?:, \d+)?>", name)
+    m = re.search(r"k_gemm_nt_pers<(\w+), (true|false)(?:, \d+)?(?:, (?:true|false))?>", name)
     if m:
         return "k_gemm_nt_pers<%s,%s>" % (m.group(1), "lower" if m.group(2) == "true" else "rect")
+    m = re.search(r"k_rbf_gram_lower_wide<(\w+), (\d)>", name)      # round 5: the lower triangle in 64 x 128 tiles
+    if m:
+        return "k_rbf_gram<%s,symmetric,d=%s>" % (m.group(1), m.group(2))
     m = re.search(r"k_rbf_gram<(\w+), (true|false), (\d)>", name)
     if m:
         return "k_rbf_gram<%s,%s,d=%s>" % (m.group(1), "symmetric" if m.group(2) == "true" else "cross", m.group(3))
