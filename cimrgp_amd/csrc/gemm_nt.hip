@@ -342,7 +342,7 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
     int t_nx = pers_tile_number(wg, 1, grid, ntiles), ti_nx = ti, tj_nx = tj;
     if (t_nx >= 0) decode(t_nx, ti_nx, tj_nx);
     bool prev_head = false;                       // the tile being stored during this pass is one the chain waits for
-    bool prv_stored = false;                      // ... or was stored directly already (head_direct)
+    bool prv_stored = true;                       // nothing to store for the "previous tile" of this pass: the first pass, or a head tile stored directly already (head_direct)
     T* c_cur = C + (int64_t)ti * GT * ldc + (int64_t)tj * GT;
     const T* a_cur = A + (int64_t)ti * GT * lda;
     const T* b_cur = B + (int64_t)tj * GT * ldb;
@@ -413,16 +413,18 @@ void k_gemm_nt_pers(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 acc0[mi][ni][r] = (c_cur + ((int64_t)(mi * 16 + RS * r) * ldc + ni * 16))[coff];
-    // The first pass has no finished tile to store, and its events store all the same (no branch around a
-    // memory instruction): the other set starts as a copy of the first tile's C, so those stores put the
-    // values just read back where they came from.
+    // The first pass has no finished tile to store, and its events store all the same (no branch around a memory
+    // instruction): it addresses the "previous tile" through a descriptor without extent (prv_stored starts true), so
+    // those stores drop.  (Rounds 3-4 copied the first tile's C into the other set and stored it back.)
+    // The barrier below is LDS-only (round 5): the first tile's C stays in flight across it and the first multiplies wait
+    // for their own accumulators only -- __syncthreads() here held every wave until all 128 KB of C had arrived.
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc1[mi][ni] = acc0[mi][ni];
+        for (int ni = 0; ni < 2; ++ni) acc1[mi][ni] = acc_zero<T>();
     PERS_SWRITE(0);
     PERS_GLOAD(a_cur, b_cur, 1);
-    __syncthreads();
+    lds_barrier();
     PERS_FRAGS(0, 0, 0);
 
     // One tile: `cur` holds its C (requested during the previous pass), `oth` the finished previous

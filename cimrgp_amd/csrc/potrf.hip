@@ -1861,6 +1861,16 @@ __global__ void k_gate(const int* __restrict__ flag, int expected, int32_t* info
     }
 }
 
+// The other direction (round 5): "panel final" from the chain's queue to the update's queue as a device word instead of
+// an event.  k_post follows the panel's last kernel in queue order and stores the panel's ordinal; on the update's queue
+// a k_gate in front of the next persistent update polls it.  Two kernels on ONE queue follow each other within a
+// microsecond or two; an event recorded on one queue and waited for on another cost 10-20 us between the end of one
+// update and the start of the next (profiles/r05_timeline_n8192.txt), twelve times per factorisation at N = 8192.
+__global__ void k_post(int* __restrict__ flag, int value)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 }  // namespace
 
 // One pass over the panels.  With FACTOR the matrix itself is factored; with
@@ -2342,6 +2352,7 @@ static int fused_sweep(T* kmat, int64_t n, int64_t ld, T* ws, int32_t* info, T* 
 // pool are created once per device and reused.
 // ---------------------------------------------------------------------------
 namespace {
+constexpr int POSTED_WORD = 32;
 constexpr int MAX_CTX = 8;               // look-ahead contexts per device: one per concurrently factoring caller stream
 constexpr int64_t SINGLE_QUEUE_MAX = 5120;   // n at or below this: one queue, no look-ahead (see potrf_run)
 
@@ -2351,7 +2362,8 @@ struct LookAhead {
     hipStream_t rows = nullptr;        // carried rows: lags behind the factorisation
     hipStream_t rows_far = nullptr;    // carried rows: far part of each panel's update (beside the rows' own panel chain)
     std::vector<hipEvent_t> ev;
-    int* flag = nullptr;               // device counter: head tiles stored by the combined update launches (k_gate polls it)
+    int* flag = nullptr;               // device counter: head tiles stored by the combined update launches (k_gate polls it);
+                                       // flag[POSTED_WORD] (a line of its own): panels posted as final by the chain (k_post)
     hipStream_t owner = nullptr;       // the caller stream this context was created for
     bool gate_ok = false;              // this context may hold a kernel that waits for another one (k_gate): the device's first context only
     std::mutex enqueue;                // one factorisation at a time enqueues on this context's queues
@@ -2374,7 +2386,7 @@ LookAhead* make_ctx(int dev)
     // process exit in the profiler runs that crashed in an exit handler.  The persistent update kernel
     // splits the machine instead: a launch of G workgroups occupies G compute units.)
     if (ok) ok = hipStreamCreateWithPriority(&la->rows, hipStreamNonBlocking, lo) == hipSuccess;
-    if (ok) ok = hipMalloc(&la->flag, 64) == hipSuccess;
+    if (ok) ok = hipMalloc(&la->flag, 256) == hipSuccess;
     // (the carried rows' second queue is created on first use: ensure_rows_far)
     if (!ok) {
         if (la->side) (void)hipStreamDestroy(la->side);
@@ -2570,8 +2582,10 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     // update (and, off the chain, the carried rows).  Cross-stream edges: "panel final"
     // (side -> main, before the bulk update that reads it) and "bulk update done" (main -> side,
     // before the next head touches columns the bulk update wrote).
-    if (may_gate) CIMRGP_HIP_TRY(hipMemsetAsync(la->flag, 0, sizeof(int), st), "hipMemsetAsync(flag)");
+    if (may_gate) CIMRGP_HIP_TRY(hipMemsetAsync(la->flag, 0, 256, st), "hipMemsetAsync(flag)");
     int flag_expected = 0;                             // head tiles the chain has been told to wait for so far
+    int posted = 0;                                    // la->flag[POSTED_WORD]: panels the chain has posted as final (k_post) so far
+    bool final_posted = false;                         // ... the panel this iteration starts from among them
     hipEvent_t ev_start = la->ev[ne++];
     CIMRGP_HIP_TRY(hipEventRecord(ev_start, st), "hipEventRecord");
     CIMRGP_HIP_TRY(hipStreamWaitEvent(sp, ev_start, 0), "hipStreamWaitEvent");
@@ -2779,6 +2793,8 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
             break;
         }
         const hipEvent_t ev_final = ev_panel;          // panel k0 is final (recorded on the side stream)
+        const bool chained = final_posted;             // ... and posted in la->flag[POSTED_WORD] as number `posted`
+        final_posted = false;
         hipEvent_t ev_go = ev_panel;                   // what the bulk stream waits for: panel k0 final ...
         const int64_t wn = (k1 < n) ? ((n - k1 < CIMRGP_NB) ? (n - k1) : CIMRGP_NB) : 0;   // next panel
         const int64_t k2 = k1 + wn;
@@ -2800,8 +2816,15 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
             // when the gate runs, instead of running the gate first and timing it out.
             hipEvent_t ev_rest_prev = ev_rest;
             flag_expected += heads;
-            // bulk queue: everything right of panel k0, the next panel's columns first
-            CIMRGP_HIP_TRY(hipStreamWaitEvent(sb, ev_final, 0), "hipStreamWaitEvent");
+            // bulk queue: everything right of panel k0, the next panel's columns first.  "Panel k0 final" reaches it as
+            // an event, or -- when the chain posted it (k_post, below) -- through a gate of its own in front of the
+            // update: the gate was enqueued after the chain it waits for, like the chain's gate after its update.
+            if (chained) {
+                hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, sb, (const int*)(la->flag + POSTED_WORD), posted, info);
+                CIMRGP_LAUNCH_CHECK("cimrgp_potrf");
+            } else {
+                CIMRGP_HIP_TRY(hipStreamWaitEvent(sb, ev_final, 0), "hipStreamWaitEvent");
+            }
             const double mm = (double)(n - k1);
             hipEvent_t rec = rec_open(sb, mm * (mm + 1.0) * (double)w, (mm * (mm + 1.0) + mm * (double)w) * (double)sizeof(T));
             GemmBatch gb = bulk_gb;
@@ -2830,6 +2853,11 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
             CIMRGP_LAUNCH_CHECK("cimrgp_potrf");
             rc = factor_panel<T>(k, n, ld, ws, info, k1, wn, sp, false, true);
             if (rc) return rc;
+            if (knobs().post_final) {
+                hipLaunchKernelGGL(k_post, dim3(1), dim3(64), 0, sp, la->flag + POSTED_WORD, ++posted);
+                CIMRGP_LAUNCH_CHECK("cimrgp_potrf");
+                final_posted = true;
+            }
             hipEvent_t ev_next = la->ev[ne++];
             CIMRGP_HIP_TRY(hipEventRecord(ev_next, sp), "hipEventRecord");
             ev_panel = ev_next;

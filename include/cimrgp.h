@@ -121,8 +121,11 @@ int cimrgp_block_posterior(int dtype, const void* x_dev, int64_t n, int d, const
  * i.  Reuse of a buffer set: behind its factorisation, `stream` waits for the solve stage of the previous call on the
  * same (stream, stream_solve) pair, so with stream_front == stream and TWO sets in rotation the caller orders nothing;
  * in every other arrangement the caller orders the reuse itself (stream_front must wait for the stream_solve work
- * that last read the set).  (Passing the previous call's k_dev or w_dev again -- one set where two are needed -- is
- * detected: the front end then waits for that call's solve stage; correct, without overlap.)  Results: k_dev is final on stream, alpha / z / mean / var on stream_solve.  Bit-identical to
+ * that last read the set).  A BUFFER SET is k_dev, w_dev, workspace_dev, alpha_dev, z_dev and scratch_dev together: the
+ * solve stage reads or writes every one of them.  The library keeps one in-flight record per (stream, stream_solve) pair
+ * and device; passing ANY buffer of a set whose solve stage may still be running -- one set where two are needed, or a
+ * plain cimrgp_block_posterior on the same set right behind a staged call -- is detected: the front end then waits for
+ * that solve stage; correct, without overlap.  Results: k_dev is final on stream, alpha / z / mean / var on stream_solve.  Bit-identical to
  * cimrgp_block_posterior; equal streams give exactly that call. */
 int cimrgp_block_posterior_staged(int dtype, const void* x_dev, int64_t n, int d, const void* y_dev, int q,
                                   const void* xs_dev, int64_t ns, double ell, double sf2, double noise,
