@@ -176,7 +176,9 @@ struct Knobs {
     int rows_step = 1;                     // CIMRGP_ROWS_STEP: carried rows' chain as one launch per panel (k_rows_step: previous panel's update + 256-wide solve; 0: update and k_trsm256 as two launches)
     int rider_lean = 1;                    // CIMRGP_RIDER_LEAN: one-queue sweeps give rounds of K = 256 riders to the links first (0: every launch starts with one round)
     int rider_round_us = 25;               // CIMRGP_RIDER_ROUND: modelled duration of one round of K = 256 rider tiles (us)
-    int rows_cus = 224;                    // CIMRGP_ROWS_CUS: compute units of the carried rows' far updates (persistent kernel; 0: tile-per-workgroup kernel)
+    int rows_cus = 192;                    // CIMRGP_ROWS_CUS: compute units of the carried rows' far updates (persistent kernel; 0: tile-per-workgroup kernel).
+                                           // Round 5, one box (profiles/r05_knob_scan.txt): 128 / 160 / 176 / 192 / 208 / 224 / 256 -> 132.0 / 135.8 / 135.8 / 136.8 / 135.4 / 133.4 /
+                                           // 130.4 posteriors/s -- two persistent workgroups fill a unit's LDS, and the chain's workgroups need units that hold at most one
     int trsm_group = 1;                    // CIMRGP_TRSM_GROUP: batched launches solve 4 row tiles per workgroup (0: one)
     int64_t rows_beside_tail_below = 2560; // CIMRGP_ROWS_BESIDE: with carried rows, the factorisation's tail (trailing matrix at most this) is the one-queue fused sweep while the rows keep their own queues (0: look-ahead to the end)
     int tail_far_cus = 160;                // CIMRGP_TAIL_FAR_CUS: compute units of FAR(prev) on the second queue of the fused tail (0: always riders)

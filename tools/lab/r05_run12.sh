@@ -1,0 +1,26 @@
+#!/bin/bash
+# round-5 GPU call 12: the schedule's thresholds once more on one box (the kernels they were tuned around got faster this round)
+mkdir -p gpurun_out
+T=$PWD/cimrgp_amd/libcimrgp_tuning.so
+one() { echo -n "$* : "; env CIMRGP_LIB_PATH=$T "$@" python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['stage_ms']['potrf_alone'])"; }
+{
+one CIMRGP_NONE=0
+one CIMRGP_CHAIN_CUS=24
+one CIMRGP_CHAIN_CUS=40
+one CIMRGP_ROWS_START=5120
+one CIMRGP_ROWS_START=7168
+one CIMRGP_NONE=0
+one CIMRGP_ROWS_CUS=192
+one CIMRGP_ROWS_CUS=240
+one CIMRGP_ROWS_BESIDE=2048
+one CIMRGP_ROWS_BESIDE=3072
+one CIMRGP_ROWS_BESIDE=3584
+one CIMRGP_NONE=0
+one CIMRGP_TAIL_BELOW=4352
+one CIMRGP_TAIL_BELOW=5376
+one CIMRGP_TAIL_FAR_CUS=128
+one CIMRGP_TAIL_FAR_CUS=192
+one CIMRGP_PERS_MIN_TILES=384
+one CIMRGP_PERS_MIN_TILES=768
+one CIMRGP_NONE=0
+} | tee gpurun_out/r05_knob_scan.txt
