@@ -615,6 +615,12 @@ def main():
         # being timed).  The profile names the source hash it was collected from: when the kernels have changed
         # since, the counters are reported as stale under `from_profile` and NOT put into the roofline.
         out["roofline"]["algorithmic_bytes_per_launch"] = tr_by.value / max(1, tr_cnt.value)
+        # The whole step against the same peak: every matrix-core flop of a step (the factorisation n^3/3, the rows carried
+        # through it (ns + q) n^2, the backward solve q n^2) over ms_per_step -- the updates above share the machine with
+        # the carried rows' updates, so the per-launch fraction understates how busy the matrix cores are kept.
+        step_flops = n ** 3 / 3.0 + (ns + q) * float(n) ** 2 + q * float(n) ** 2
+        step_tflops = step_flops / (dt / args.steps) / 1e12          # per GPU (every rank runs one step per step)
+        out["roofline"]["whole_step"] = {"flops_per_step": step_flops, "achieved": step_tflops, "frac": step_tflops / peak}
         pmc = os.path.join(ROOT, "profiles", PMC_PROFILE)
         if args.dtype == "f64" and n == 8192 and os.path.exists(pmc):
             with open(pmc) as fh:

@@ -46,6 +46,7 @@ const Knobs& knobs()
         v.pers_max_chunks = (int)num("CIMRGP_PERS_CHUNKS", v.pers_max_chunks);
         v.head_direct_max_rounds = (int)num("CIMRGP_HEAD_DIRECT", v.head_direct_max_rounds);
         v.post_final = (int)num("CIMRGP_POST_FINAL", v.post_final);
+        v.heads_beside_rows = (int)num("CIMRGP_HEADS_ROWS", v.heads_beside_rows);
         v.pers_flex_cus = (int)num("CIMRGP_PERS_FLEX", v.pers_flex_cus);
         v.pers_flex_min_rounds = (int)num("CIMRGP_PERS_FLEX_MIN", v.pers_flex_min_rounds);
         v.rows_fused_tail = (int)num("CIMRGP_ROWS_FUSED", v.rows_fused_tail);

@@ -2806,7 +2806,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
         // 64 x 64 update as its prologue (as before) and the rest of the first 128 x 128 tile along as riders.
         // (not while the carried rows are running: their kernels hold compute units the persistent workgroups
         // of the combined launch -- head tiles included -- would have to wait for: 114 -> 109 posteriors/s)
-        const bool rows_running = rows && !rows_fused && (n - k1 <= knobs().rows_start_below);
+        const bool rows_running = rows && !rows_fused && !knobs().heads_beside_rows && (n - k1 <= knobs().rows_start_below);
         const int heads = (may_gate && knobs().chain_mode == 0 && !rows_running && w == CIMRGP_NB && wn == CIMRGP_NB && n > k2 && !grp_open() &&
                            group_size(n - k2 - ((n - k2 < CIMRGP_NB) ? (n - k2) : CIMRGP_NB), knobs().far_pair_above) == 1)
                               ? gemm_pers_head_tiles(n - k1, (int)w, (int)sizeof(T)) : 0;
