@@ -394,7 +394,9 @@ def main():
     streams = None                                                                    # front, factor, solve
     if pipeline:
         cur = torch.cuda.current_stream()
-        streams = (cur, cur, dev.solve_queue(cur))
+        # front end of step i+1 on the context's chain queue, which falls idle in the last third of step i's factorisation
+        # (cimrgp_front_queue; one box, three alternating pairs: 136.8 / 136.9 / 136.6 -> 137.4 / 137.2 / 137.3 posteriors/s)
+        streams = (dev.front_queue(cur) if os.environ.get("CIMRGP_BENCH_FRONT", "1") == "1" else cur, cur, dev.solve_queue(cur))
     pending = [None] * nsets                 # the set's collective in flight
     done = [None] * nsets                    # (pipeline) the set's last reader on the solve stream
     step_no = [0]
@@ -583,7 +585,8 @@ def main():
             "cholesky_frac_of_peak": chol_gflops / 1e3 / peak,
             "step_is": ("ONE cimrgp_block_posterior_staged call per step on preallocated buffers (+ the collective's enqueue): consecutive steps "
                         "are independent blocks over two rotating buffer sets; the backward solve and prediction of step i run on the "
-                        "look-ahead context's idle queue (cimrgp_solve_queue) beside the Gram matrices and first panels of step i+1; "
+                        "look-ahead context's idle queue (cimrgp_solve_queue) beside the first panels of step i+1, whose Gram matrices run on the "
+                        "context's chain queue (cimrgp_front_queue) beside the last panels of step i; "
                         "every step completes inside the timed region")
                        if pipeline else "ONE cimrgp_block_posterior call per step on preallocated buffers (+ the collective's enqueue)",
             "pipelined_steps": bool(pipeline),

@@ -30,6 +30,7 @@ SIGNATURES = {
     "cimrgp_block_posterior_staged": (_i32, [_i32, _vp, _i64, _i32, _vp, _i32, _vp, _i64, _dbl, _dbl, _dbl, _vp, _i64, _vp, _sz, _vp, _vp,
                                              _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "cimrgp_solve_queue": (_i32, [_vp, C.POINTER(C.c_void_p)]),
+    "cimrgp_front_queue": (_i32, [_vp, C.POINTER(C.c_void_p)]),
     "cimrgp_potrf_rows_batched": (_i32, [_i32, _vp, _i64, _i64, _i64, _vp, _sz, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
     "cimrgp_solve_lt_batched": (_i32, [_i32, _vp, _i64, _i64, _i64, _vp, _sz, _vp, _i32, _vp, _i32, _vp]),
     "cimrgp_solve_lt": (_i32, [_i32, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _vp]),

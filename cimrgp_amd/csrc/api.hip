@@ -135,6 +135,8 @@ namespace {
 struct StagedRec_ {
     hipStream_t st = nullptr, solve = nullptr;
     hipEvent_t event = nullptr;
+    hipEvent_t prev_event = nullptr;           // behind the solve stage of the pair's call BEFORE the latest (has_prev)
+    bool has_prev = false;
     bool live = false;
     unsigned long long age = 0;
     const void* buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -158,11 +160,11 @@ static int staged_shutdown_()
         StagedDev_& sd = staged_devs_()[d];
         std::lock_guard<std::mutex> guard(sd.m);
         bool any = false;
-        for (auto& r : sd.rec) any = any || r.event != nullptr;
+        for (auto& r : sd.rec) any = any || r.event != nullptr || r.prev_event != nullptr;
         for (auto& e : sd.ring) any = any || e != nullptr;
         if (!any) continue;
         (void)hipSetDevice(d);
-        for (auto& r : sd.rec) { if (r.event) (void)hipEventDestroy(r.event); r = StagedRec_(); }
+        for (auto& r : sd.rec) { if (r.event) (void)hipEventDestroy(r.event); if (r.prev_event) (void)hipEventDestroy(r.prev_event); r = StagedRec_(); }
         for (auto& e : sd.ring) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     }
     if (have_cur) (void)hipSetDevice(cur);
@@ -214,6 +216,21 @@ int block_posterior_typed(const void* x, int64_t n, int d, const void* y, int q,
             if (shares) rc = check_hip(hipStreamWaitEvent(s_front, r.event, 0), fn, "hipStreamWaitEvent");
         }
     }
+    // Safety net 3 (round 5): a front stream of its own (cimrgp_front_queue: the front end beside the PREVIOUS call's
+    // factorisation) is not ordered behind anything the earlier calls did on `st`.  The latest call of the pair is covered
+    // by net 1 when it shares a buffer; every call before it by one wait for the solve stage of the call before the
+    // latest (the solve queue is in order, so that covers all older ones; it finished a factorisation ago: no cost).
+    // Without a solve queue of its own there are no records: the front stream then simply follows `st`.
+    if (!rc && s_front != st) {
+        if (s_solve == st) {
+            rc = hand_over(st, s_front);
+        } else {
+            std::lock_guard<std::mutex> guard(sd.m);
+            for (auto& r : sd.rec)
+                if (r.live && r.has_prev && r.st == st && r.solve == s_solve && !rc)
+                    rc = check_hip(hipStreamWaitEvent(s_front, r.prev_event, 0), fn, "hipStreamWaitEvent");
+        }
+    }
     // front end: the Gram matrix, the cross-Gram matrix and the targets as carried rows
     if (!rc) rc = rbf_gram_run<T>((const T*)x, n, (const T*)x, n, d, ell, sf2, noise, (T*)k, ldk, true, true, s_front);
     if (!rc && ns > 0) rc = rbf_gram_run<T>((const T*)xs, ns, (const T*)x, n, d, ell, sf2, 0.0, wt, ldw, false, false, s_front);
@@ -242,11 +259,18 @@ int block_posterior_typed(const void* x, int64_t n, int d, const void* y, int q,
         std::lock_guard<std::mutex> guard(sd.m);
         StagedRec_* slot = nullptr;
         for (auto& r : sd.rec) if (r.live && r.st == st && r.solve == s_solve) slot = &r;
-        if (!slot) for (auto& r : sd.rec) if (!r.live && !slot) slot = &r;
-        if (!slot) {
-            slot = &sd.rec[0];
-            for (auto& r : sd.rec) if (r.age < slot->age) slot = &r;
-            (void)hipEventSynchronize(slot->event);
+        if (slot) {
+            // the pair's own record: the latest call becomes "the one before", its event is kept; the older event is recorded again
+            std::swap(slot->event, slot->prev_event);
+            slot->has_prev = true;
+        } else {
+            for (auto& r : sd.rec) if (!r.live && !slot) slot = &r;
+            if (!slot) {
+                slot = &sd.rec[0];
+                for (auto& r : sd.rec) if (r.age < slot->age) slot = &r;
+                (void)hipEventSynchronize(slot->event);
+            }
+            slot->has_prev = false;
         }
         if (slot->event == nullptr && hipEventCreateWithFlags(&slot->event, hipEventDisableTiming) != hipSuccess) {
             slot->event = nullptr;
@@ -358,6 +382,14 @@ int cimrgp_solve_queue(void* stream, void** queue_out)
     const char* fn = "cimrgp_solve_queue";
     CIMRGP_REQUIRE(queue_out != nullptr, fn, "null pointer");
     *queue_out = (void*)cimrgp::solve_queue_for(S(stream));
+    return 0;
+}
+
+int cimrgp_front_queue(void* stream, void** queue_out)
+{
+    const char* fn = "cimrgp_front_queue";
+    CIMRGP_REQUIRE(queue_out != nullptr, fn, "null pointer");
+    *queue_out = (void*)cimrgp::front_queue_for(S(stream));
     return 0;
 }
 

@@ -201,6 +201,8 @@ int rows_queues();
 static inline int64_t bwd_pairs(int64_t n) { return (n > 5120) ? (n / CIMRGP_NB) / 2 : 0; }
 // (potrf.hip) the look-ahead context's queue that is idle between two factorisations on st: cimrgp_solve_queue
 hipStream_t solve_queue_for(hipStream_t st);
+// (potrf.hip) the context's queue that falls idle before a factorisation on st ends: cimrgp_front_queue
+hipStream_t front_queue_for(hipStream_t st);
 
 // --------------------------------------------------------- host launchers ----
 // potrf.hip

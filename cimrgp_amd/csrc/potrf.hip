@@ -2480,6 +2480,15 @@ hipStream_t solve_queue_for(hipStream_t st)
 }
 
 
+// The queue of `st`'s look-ahead context that falls idle BEFORE a factorisation on `st` ends (the panel chain's queue: the
+// last third of a factorisation runs on one queue, potrf_run's tail): the front end of the NEXT independent block can run
+// there beside that tail (cimrgp_front_queue).  `st` itself when it owns no context.
+hipStream_t front_queue_for(hipStream_t st)
+{
+    LookAhead* la = acquire_ctx(st);
+    return (la != nullptr && la->owner == st && la->side != nullptr) ? la->side : st;
+}
+
 int potrf_shutdown()
 {
     {

@@ -170,6 +170,19 @@ def solve_queue(stream=None):
     return torch.cuda.ExternalStream(out.value, device=cur.device)
 
 
+def front_queue(stream=None):
+    """The stream to pass as ``streams[0]`` of :func:`block_posterior` when consecutive calls are independent blocks
+    (cimrgp_front_queue, include/cimrgp.h): the look-ahead context's queue that falls idle before a factorisation on
+    ``stream`` ends, wrapped as a torch stream; ``stream`` itself when it owns no context."""
+    lib = _lib.load()
+    cur = torch.cuda.current_stream() if stream is None else stream
+    out = ctypes.c_void_p()
+    _lib.check(lib.cimrgp_front_queue(cur.cuda_stream, ctypes.byref(out)), "cimrgp_front_queue")
+    if (out.value or 0) == (cur.cuda_stream or 0):
+        return cur
+    return torch.cuda.ExternalStream(out.value, device=cur.device)
+
+
 def potrf_rows_batched(karena, n, ld, ws_arena, info, barena=None, m=0, ldb=0):
     """``batch`` equal-sized factorisations in the same launches.  karena: (batch, n, ld) tensor,
     ws_arena: (batch, ws_bytes) uint8, info: (batch,) int32, barena: (batch, m, ldb) carried rows."""

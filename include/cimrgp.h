@@ -139,6 +139,11 @@ int cimrgp_block_posterior_staged(int dtype, const void* x_dev, int64_t n, int d
  * caller orders its own reads of the solve stage's results (an event on *queue_out).  *queue_out = stream when no
  * context can be had for `stream` (then nothing overlaps).  The queue lives until cimrgp_shutdown. */
 int cimrgp_solve_queue(void* stream, void** queue_out);
+/* A queue for stream_front: the queue of `stream`'s look-ahead context that falls idle before a factorisation on
+ * `stream` ends (the last third of a factorisation runs on one queue).  The Gram matrices of the NEXT independent block,
+ * enqueued there, run beside that latency-bound tail instead of behind it.  The caller orders the front end's inputs
+ * on *queue_out itself (the staged call orders its own buffer sets).  *queue_out = stream when no context can be had. */
+int cimrgp_front_queue(void* stream, void** queue_out);
 /* `batch` equal-sized factorisations -- the blocks of one layer (independent over regions,
  * Posteriors.py:35-59) -- in the SAME kernel launches: matrix i starts k_stride elements after
  * matrix i-1 (likewise workspace_stride_bytes, b_stride), info_dev holds `batch` int32.  One queue

@@ -508,13 +508,16 @@ def test_potrf_rows_batched_matches_single(dev, dt, tol, n, batch, m):
         assert got[1] > 0 and all(g == 0 for j, g in enumerate(got) if j != 1)
 
 
+@pytest.mark.parametrize("front", [False, True])
 @pytest.mark.parametrize("nsets", [2, 1])
 @pytest.mark.parametrize("n,ns,q", [(700, 50, 2), (5632, 130, 2)])
-def test_block_posterior_solve_stage_on_the_idle_context_queue(dev, n, ns, q, nsets):
+def test_block_posterior_solve_stage_on_the_idle_context_queue(dev, n, ns, q, nsets, front):
     """cimrgp_solve_queue: the solve stage of block i on the look-ahead context's idle queue, beside the front end and
     first panels of block i+1, over TWO rotating buffer sets with no ordering by the caller other than its own reads:
     bit for bit the one-stream results (small n: the factorisation itself does not use the context).  With ONE buffer set
-    (a caller's mistake) the front end waits for the previous solve stage: still the right results, no overlap."""
+    (a caller's mistake) the front end waits for the previous solve stage: still the right results, no overlap.
+    front: the front end on cimrgp_front_queue (the context's chain queue, idle in a factorisation's last third), so that
+    block i+1's Gram matrices run beside block i's factorisation -- the same results, ordered by the call's own nets."""
     tdt = torch.float64
     nblocks = 5
     rng = np.random.default_rng(n + 1)
@@ -541,11 +544,13 @@ def test_block_posterior_solve_stage_on_the_idle_context_queue(dev, n, ns, q, ns
     cur = torch.cuda.current_stream()
     sq = dev.solve_queue(cur)
     assert sq.cuda_stream != cur.cuda_stream
+    fq = dev.front_queue(cur) if front else cur
+    assert (fq.cuda_stream != cur.cuda_stream and fq.cuda_stream != sq.cuda_stream) or not front
     sets = [buffers() for _ in range(nsets)]
     for i, (xd, yd, xsd) in enumerate(blocks):
         b = sets[i % nsets]
         dev.block_posterior(xd, yd, xsd, ell, sf2, noise, b["kbuf"], b["wbuf"], b["ws"], b["info"], b["alpha"], b["z"],
-                            means[nblocks + i], vars_[nblocks + i], scratch=b["scratch"], streams=(cur, cur, sq))
+                            means[nblocks + i], vars_[nblocks + i], scratch=b["scratch"], streams=(fq, cur, sq))
     torch.cuda.synchronize()
     for i in range(nblocks):
         assert torch.equal(means[i], means[nblocks + i]) and torch.equal(vars_[i], vars_[nblocks + i])
