@@ -120,7 +120,7 @@ static int layer_predict_typed(const void* x, const int64_t* starts, int64_t n, 
 namespace cimrgp {
 // (layer.hip) the targets as carried rows, rows[c][j] = y[j][c]; and back: z[j][c] = alpha[j][c] = rows[c][j]
 template <typename T> int rhs_rows_run(const T* y, int64_t n, int q, T* rows, int64_t ldr, hipStream_t st);
-template <typename T> int rows_to_z_run(const T* rows, int64_t ldr, int64_t n, int q, T* z, T* alpha, hipStream_t st);
+template <typename T> int rows_to_z_run(const T* rows, int64_t ldr, int64_t n, int q, T* z, T* alpha, hipStream_t st, T* work = nullptr);
 }  // namespace cimrgp
 
 namespace {
@@ -249,8 +249,8 @@ int block_posterior_typed(const void* x, int64_t n, int d, const void* y, int q,
                 rc = check_hip(hipStreamWaitEvent(st, r.event, 0), fn, "hipStreamWaitEvent");
     }
     // z = L^-1 y (the last q carried rows), alpha = L^-T z, mean = W z, var = sf2 - sum W^2 (+ noise)
-    if (!rc) rc = rows_to_z_run<T>(wt + ns * ldw, ldw, n, q, (T*)z, (T*)alpha, s_solve);
-    if (!rc) rc = potrs_run<T>((const T*)k, n, ldk, (const T*)ws, (T*)alpha, q, nullptr, (T*)scratch, true, s_solve);
+    if (!rc) rc = rows_to_z_run<T>(wt + ns * ldw, ldw, n, q, (T*)z, (T*)alpha, s_solve, (T*)scratch);
+    if (!rc) rc = potrs_run<T>((const T*)k, n, ldk, (const T*)ws, (T*)alpha, q, nullptr, (T*)scratch, true, s_solve, PotrfBatch(), true);
     if (!rc && ns > 0) rc = predict_from_w_run<T>((const T*)w, ns, n, ldw, (const T*)z, q, sf2, add_noise ? noise : 0.0, nullptr, nullptr,
                                                    (T*)mean, (T*)var, accumulate, s_solve, 1, nullptr, 0);
     if (!rc && s_solve != st) {

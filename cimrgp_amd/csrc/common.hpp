@@ -240,7 +240,7 @@ template <typename T> int predict_mean_run(const T* x, int64_t n, int d, const T
                                            double ell, double sf2, const T* bias, T* mean, int accumulate, hipStream_t st);
 // solve.hip
 template <typename T> int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* z_out, T* scratch,
-                                    bool backward_only, hipStream_t st, PotrfBatch bt = PotrfBatch());
+                                    bool backward_only, hipStream_t st, PotrfBatch bt = PotrfBatch(), bool work_ready = false);
 template <typename T> int predict_from_w_run(const T* w, int64_t ns, int64_t n, int64_t ldw, const T* z, int q, double sf2,
                                              double extra, const T* extra_dev, const T* bias, T* mean, T* var, int accumulate,
                                              hipStream_t st, int batch = 1, const int64_t* t_starts = nullptr, int64_t sw = 0);

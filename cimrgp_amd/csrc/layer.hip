@@ -95,7 +95,7 @@ __global__ void k_layer_rows(const T* __restrict__ y, const T* __restrict__ fbar
 // z[b][j][c] = alpha0[b][j][c] = rows[b][c][j] (z = L^-1 r after the factorisation; alpha0 is solved in place)
 template <typename T>
 __global__ void k_layer_z(const T* __restrict__ rows, int64_t ldr, int64_t srows, int64_t n, int q, T* __restrict__ z,
-                          T* __restrict__ alpha)
+                          T* __restrict__ alpha, T* __restrict__ work, int64_t swork)
 {
     const int b = blockIdx.y;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -105,6 +105,8 @@ __global__ void k_layer_z(const T* __restrict__ rows, int64_t ldr, int64_t srows
     const T v = rows[(int64_t)b * srows + (int64_t)c * ldr + j];
     z[(int64_t)b * n * q + e] = v;
     alpha[(int64_t)b * n * q + e] = v;
+    // the backward solve's running right-hand side (q x n per problem, potrs_run: `work`), so that it need not transpose alpha first
+    if (work) work[(int64_t)b * swork + (int64_t)c * n + j] = v;
 }
 
 // train_out += K_noiseless alpha + bias = (y - f_bar - bias) - noise alpha + bias = y - f_bar - noise alpha
@@ -148,9 +150,10 @@ int layer_fit_run(const LayerFit<T>& a, hipStream_t st)
     bt.sb = a.srows;
     rc = potrf_batched_run<T>(a.k, a.n, a.ldk, a.ws, a.info, a.rows, a.q, a.ldr, bt, st);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_layer_z<T>), dim3(ge, nb), dim3(256), 0, st, (const T*)a.rows, a.ldr, a.srows, a.n, a.q, a.z, a.alpha);
+    hipLaunchKernelGGL((k_layer_z<T>), dim3(ge, nb), dim3(256), 0, st, (const T*)a.rows, a.ldr, a.srows, a.n, a.q, a.z, a.alpha,
+                       a.scratch, 2 * (int64_t)a.q * a.n);
     CIMRGP_LAUNCH_CHECK(fn);
-    rc = potrs_run<T>(a.k, a.n, a.ldk, a.ws, a.alpha, a.q, nullptr, a.scratch, true, st, bt);
+    rc = potrs_run<T>(a.k, a.n, a.ldk, a.ws, a.alpha, a.q, nullptr, a.scratch, true, st, bt, true);
     if (rc) return rc;
     hipLaunchKernelGGL((k_layer_train_mean<T>), dim3(ge, nb), dim3(256), 0, st, a.y, a.fbar, a.starts, a.n, a.q,
                        (const T*)a.alpha, (const T*)a.noise, a.train_out);
@@ -204,18 +207,19 @@ int rhs_rows_run(const T* y, int64_t n, int q, T* rows, int64_t ldr, hipStream_t
 }
 
 template <typename T>
-int rows_to_z_run(const T* rows, int64_t ldr, int64_t n, int q, T* z, T* alpha, hipStream_t st)
+int rows_to_z_run(const T* rows, int64_t ldr, int64_t n, int q, T* z, T* alpha, hipStream_t st, T* work)
 {
     if (n <= 0 || q <= 0) return 0;
-    hipLaunchKernelGGL((k_layer_z<T>), dim3((unsigned)((n * q + 255) / 256), 1), dim3(256), 0, st, rows, ldr, (int64_t)0, n, q, z, alpha);
+    hipLaunchKernelGGL((k_layer_z<T>), dim3((unsigned)((n * q + 255) / 256), 1), dim3(256), 0, st, rows, ldr, (int64_t)0, n, q, z, alpha,
+                       work, (int64_t)0);
     CIMRGP_LAUNCH_CHECK("cimrgp_block_posterior");
     return 0;
 }
 
 template int rhs_rows_run<double>(const double*, int64_t, int, double*, int64_t, hipStream_t);
 template int rhs_rows_run<float>(const float*, int64_t, int, float*, int64_t, hipStream_t);
-template int rows_to_z_run<double>(const double*, int64_t, int64_t, int, double*, double*, hipStream_t);
-template int rows_to_z_run<float>(const float*, int64_t, int64_t, int, float*, float*, hipStream_t);
+template int rows_to_z_run<double>(const double*, int64_t, int64_t, int, double*, double*, hipStream_t, double*);
+template int rows_to_z_run<float>(const float*, int64_t, int64_t, int, float*, float*, hipStream_t, float*);
 template int layer_fit_run<double>(const LayerFit<double>&, hipStream_t);
 template int layer_fit_run<float>(const LayerFit<float>&, hipStream_t);
 template int layer_predict_run<double>(const LayerPredict<double>&, hipStream_t);

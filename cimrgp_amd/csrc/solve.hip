@@ -211,8 +211,10 @@ void k_bwd_alpha2(const T* __restrict__ invT, const T* __restrict__ xoff, int n,
     }
 }
 
-// PWU = rows of the step: one panel (256) or a pair (512)
-template <typename T, int Q, int PWU = PW>
+// PWU = rows of the step: one panel (256) or a pair (512).  COLS = columns per workgroup: 64, or (round 5, single matrices)
+// one 128-byte line per row -- a workgroup then streams 64 KB instead of 256 KB and four times as many of them share a
+// step; the step's time is one workgroup's time (k_bwd_update at n = 8192: 8.9-10 us per step whatever the width left).
+template <typename T, int Q, int PWU = PW, int COLS = SB>
 __global__ __launch_bounds__(ST)
 void k_bwd_update(const T* __restrict__ L, int64_t ld, int n, T* __restrict__ work, const T* __restrict__ alpha,
                   int k0, int w, int64_t sk = 0, int64_t sscr = 0)
@@ -220,13 +222,19 @@ void k_bwd_update(const T* __restrict__ L, int64_t ld, int n, T* __restrict__ wo
     L += (int64_t)blockIdx.y * sk;
     work += (int64_t)blockIdx.y * sscr;
     alpha += (int64_t)blockIdx.y * sscr;
-    constexpr int RPP = PWU / 16;                                 // rows per part
+    constexpr int PARTS = ST / COLS;                              // row parts: 16 (64 columns) ... 64 (16 columns)
+    constexpr int RPP = PWU / PARTS;                              // rows per part
+    static_assert(ST % COLS == 0 && PWU % PARTS == 0 && RPP >= 1, "k_bwd_update: the step's rows split evenly over the parts");
     __shared__ T zs[Q][PWU];
-    __shared__ T red[16][Q][SB];
+    __shared__ T red[PARTS][Q][COLS];
     const int tid = threadIdx.x;
-    const int t = tid & 63, part = tid >> 6;                      // 16 row parts
-    const int col = blockIdx.x * SB + t;
+    const int t = tid % COLS, part = tid / COLS;
+    const int col = blockIdx.x * COLS + t;
     const int ubeg = part * RPP;
+    // the value this thread will update at the end (threads 0 .. Q COLS - 1), requested now: one round trip less behind the sums
+    const int oc = tid / COLS, ocol = blockIdx.x * COLS + (tid - oc * COLS);
+    const bool owner = (tid < Q * COLS) && (ocol < k0);
+    const T wold = owner ? work[(int64_t)oc * n + ocol] : (T)0;
     T lv[RPP];
     if (col < k0) {
         const T* lp = L + (int64_t)k0 * ld + col;
@@ -259,14 +267,12 @@ void k_bwd_update(const T* __restrict__ L, int64_t ld, int n, T* __restrict__ wo
     for (int c = 0; c < Q; ++c)
         red[part][c][t] = acc[c];
     __syncthreads();
-    if (part == 0 && col < k0) {
+    // one thread per (output, column): the parts in their fixed order
+    if (owner) {
+        T sv = (T)0;
 #pragma unroll
-        for (int c = 0; c < Q; ++c) {
-            T sv = (T)0;
-#pragma unroll
-            for (int pp = 0; pp < 16; ++pp) sv += red[pp][c][t];
-            work[(int64_t)c * n + col] -= sv;
-        }
+        for (int pp = 0; pp < PARTS; ++pp) sv += red[pp][oc][tid - oc * COLS];
+        work[(int64_t)oc * n + ocol] = wold - sv;
     }
 }
 
@@ -288,9 +294,11 @@ void k_predict_from_w(const T* __restrict__ W, int ns, int n, int64_t ldw, const
         if (mean) mean += t_starts[b] * q;
         if (var) var += t_starts[b];
     }
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= ns) return;
+    // Round 5: one ROW per workgroup, a quarter of it per wave (until then one row per wave: 2048 waves for the bench's
+    // W, two per SIMD, 4 KB in flight each -- 134 MB in 60-80 us; four times the waves keep four times the bytes in flight).
+    // The four partial sums are combined in wave order (fixed: bit-identical on repetition).
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x;
     const T* wp = W + (int64_t)row * ldw;
     T ss = (T)0;
     T sm[Q];
@@ -298,10 +306,12 @@ void k_predict_from_w(const T* __restrict__ W, int ns, int n, int64_t ldw, const
     for (int c = 0; c < Q; ++c) sm[c] = (T)0;
     const bool want_mean = (mean != nullptr) && (z != nullptr);
     // rows start on a 128-byte line (ldw is a multiple of 16 elements): two elements per lane and
-    // load, four independent loads in flight per lane
+    // load, eight independent loads in flight per lane
     const int n2 = n & ~1;
-#pragma unroll 4
-    for (int j = 2 * lane; j < n2; j += 128) {
+    const int chunk = (((n2 + 3) / 4 + 127) / 128) * 128;        // elements per wave: whole 128-element sweeps
+    const int jend = (n2 < (wave + 1) * chunk) ? n2 : (wave + 1) * chunk;
+#pragma unroll 8
+    for (int j = wave * chunk + 2 * lane; j < jend; j += 128) {
         const T w0 = wp[j], w1 = wp[j + 1];
         ss += w0 * w0;
         ss += w1 * w1;
@@ -313,7 +323,7 @@ void k_predict_from_w(const T* __restrict__ W, int ns, int n, int64_t ldw, const
             }
         }
     }
-    if (n2 < n && lane == 0) {
+    if (n2 < n && lane == 0 && wave == 3) {
         const T w = wp[n2];
         ss += w * w;
         if (want_mean) {
@@ -328,7 +338,25 @@ void k_predict_from_w(const T* __restrict__ W, int ns, int n, int64_t ldw, const
         for (int c = 0; c < Q; ++c)
             sm[c] += __shfl_xor(sm[c], off, 64);
     }
+    __shared__ T part[4][Q + 1];
     if (lane == 0) {
+        part[wave][Q] = ss;
+#pragma unroll
+        for (int c = 0; c < Q; ++c) part[wave][c] = sm[c];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ss = part[0][Q];
+#pragma unroll
+        for (int c = 0; c < Q; ++c) sm[c] = part[0][c];
+#pragma unroll
+        for (int w4 = 1; w4 < 4; ++w4) {
+            ss += part[w4][Q];
+#pragma unroll
+            for (int c = 0; c < Q; ++c) sm[c] += part[w4][c];
+        }
+    }
+    if (threadIdx.x == 0) {
         if (var) { const T v = sf2_plus + (extra_dev ? extra_dev[0] : (T)0) - ss; var[row] = accumulate ? var[row] + v : v; }
         if (want_mean) {
 #pragma unroll
@@ -360,7 +388,7 @@ void k_predict_from_w(const T* __restrict__ W, int ns, int n, int64_t ldw, const
 
 template <typename T>
 int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* z_out, T* scratch,
-              bool backward_only, hipStream_t st, PotrfBatch bt)
+              bool backward_only, hipStream_t st, PotrfBatch bt, bool work_ready)
 {
     const char* fn = "cimrgp_potrs";
     if (n <= 0) return 0;
@@ -374,8 +402,13 @@ int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* 
     T* work = scratch;             // (q x n) running right-hand side
     T* res  = scratch + q * n;     // (q x n) solved blocks
     const unsigned tg = (unsigned)((n * q + 255) / 256);
-    hipLaunchKernelGGL((k_transpose_nq<T>), dim3(tg, nbatch), dim3(256), 0, st, (const T*)rhs, work, n, q, 1, srhs, sscr);
-    CIMRGP_LAUNCH_CHECK(fn);
+    // work_ready (backward half only): the caller has put the right-hand sides into `work` itself (k_layer_z writes them
+    // there beside z: one launch less in front of a chain of dependent launches)
+    CIMRGP_REQUIRE(!work_ready || backward_only, fn, "a prepared right-hand side is for the backward half");
+    if (!work_ready) {
+        hipLaunchKernelGGL((k_transpose_nq<T>), dim3(tg, nbatch), dim3(256), 0, st, (const T*)rhs, work, n, q, 1, srhs, sscr);
+        CIMRGP_LAUNCH_CHECK(fn);
+    }
     const T* invT = ws + ((n + SB - 1) / SB) * (SB * SB);
     for (int64_t k0 = 0; k0 < n && !backward_only; k0 += PW) {
         const int w = (int)((n - k0 < PW) ? (n - k0) : PW);
@@ -398,6 +431,9 @@ int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* 
         hipError_t e = hipMemcpyAsync(work, res, sizeof(T) * (size_t)(q * n), hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return check_hip(e, fn, "hipMemcpyAsync");
     }   // backward_only: `work` already holds z (RHS-major), put there by the first transpose
+    // single matrices: one 128-byte line of L per row and workgroup (k_bwd_update); a batch of blocks has workgroups enough
+    constexpr int LINE = 128 / (int)sizeof(T);
+    const bool narrow = (nbatch == 1);
     const int64_t last = ((n - 1) / PW) * PW;
     const int64_t npairs = bwd_pairs(n);                           // pairs of full panels: two per step (k_bwd_alpha2)
     const T* xoff = invT + ((n + PW - 1) / PW) * (PW * PW);
@@ -407,7 +443,11 @@ int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* 
         CIMRGP_Q_SWITCH(q, hipLaunchKernelGGL((k_bwd_alpha<T, QQ>), dim3((unsigned)((w + 3) / 4), nbatch), dim3(256), 0, st,
                                               invT, (int)n, (const T*)work, res, (int)k0, w, bt.sws, sscr));
         CIMRGP_LAUNCH_CHECK(fn);
-        if (grid) {
+        if (grid && narrow) {
+            CIMRGP_Q_SWITCH(q, hipLaunchKernelGGL((k_bwd_update<T, QQ, PW, LINE>), dim3((unsigned)((k0 + LINE - 1) / LINE), nbatch), dim3(ST), 0, st,
+                                                  l, ld, (int)n, work, (const T*)res, (int)k0, w, bt.sk, sscr));
+            CIMRGP_LAUNCH_CHECK(fn);
+        } else if (grid) {
             CIMRGP_Q_SWITCH(q, hipLaunchKernelGGL((k_bwd_update<T, QQ>), dim3(grid, nbatch), dim3(ST), 0, st, l, ld, (int)n,
                                                   work, (const T*)res, (int)k0, w, bt.sk, sscr));
             CIMRGP_LAUNCH_CHECK(fn);
@@ -419,7 +459,11 @@ int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* 
         CIMRGP_Q_SWITCH(q, hipLaunchKernelGGL((k_bwd_alpha2<T, QQ>), dim3(2 * PW / 4, nbatch), dim3(256), 0, st,
                                               invT, xoff, (int)n, (const T*)work, res, (int)k0, bt.sws, sscr));
         CIMRGP_LAUNCH_CHECK(fn);
-        if (grid) {
+        if (grid && narrow) {
+            CIMRGP_Q_SWITCH(q, hipLaunchKernelGGL((k_bwd_update<T, QQ, 2 * PW, LINE>), dim3((unsigned)((k0 + LINE - 1) / LINE), nbatch), dim3(ST), 0, st,
+                                                  l, ld, (int)n, work, (const T*)res, (int)k0, 2 * PW, bt.sk, sscr));
+            CIMRGP_LAUNCH_CHECK(fn);
+        } else if (grid) {
             CIMRGP_Q_SWITCH(q, hipLaunchKernelGGL((k_bwd_update<T, QQ, 2 * PW>), dim3(grid, nbatch), dim3(ST), 0, st, l, ld, (int)n,
                                                   work, (const T*)res, (int)k0, 2 * PW, bt.sk, sscr));
             CIMRGP_LAUNCH_CHECK(fn);
@@ -440,15 +484,15 @@ int predict_from_w_run(const T* w, int64_t ns, int64_t n, int64_t ldw, const T* 
     CIMRGP_REQUIRE(q >= 0 && q <= MAXQ, fn, "number of outputs must be <= 8");
     CIMRGP_REQUIRE(ns < (1ll << 31) && n < (1ll << 31) && batch < 65536, fn, "too many points");
     CIMRGP_REQUIRE(batch == 1 || t_starts != nullptr, fn, "a batch needs the blocks' test offsets");
-    CIMRGP_Q_SWITCH(q > 0 ? q : 1, hipLaunchKernelGGL((k_predict_from_w<T, QQ>), dim3((unsigned)((ns + 3) / 4), (unsigned)batch), dim3(256), 0, st,
+    CIMRGP_Q_SWITCH(q > 0 ? q : 1, hipLaunchKernelGGL((k_predict_from_w<T, QQ>), dim3((unsigned)ns, (unsigned)batch), dim3(256), 0, st,
                                                       w, (int)ns, (int)n, ldw, z, q, (T)(sf2 + extra), extra_dev, bias, mean, var, accumulate,
                                                       t_starts, sw));
     CIMRGP_LAUNCH_CHECK(fn);
     return 0;
 }
 
-template int potrs_run<double>(const double*, int64_t, int64_t, const double*, double*, int, double*, double*, bool, hipStream_t, PotrfBatch);
-template int potrs_run<float>(const float*, int64_t, int64_t, const float*, float*, int, float*, float*, bool, hipStream_t, PotrfBatch);
+template int potrs_run<double>(const double*, int64_t, int64_t, const double*, double*, int, double*, double*, bool, hipStream_t, PotrfBatch, bool);
+template int potrs_run<float>(const float*, int64_t, int64_t, const float*, float*, int, float*, float*, bool, hipStream_t, PotrfBatch, bool);
 template int predict_from_w_run<double>(const double*, int64_t, int64_t, int64_t, const double*, int, double, double,
                                         const double*, const double*, double*, double*, int, hipStream_t, int, const int64_t*, int64_t);
 template int predict_from_w_run<float>(const float*, int64_t, int64_t, int64_t, const float*, int, double, double,
