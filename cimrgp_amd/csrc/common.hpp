@@ -187,7 +187,11 @@ struct Knobs {
     int pers_max_chunks = 2;               // CIMRGP_PERS_CHUNKS: the persistent update takes K up to this many panels (256 columns each) in one pass per tile (1: K = 256 only, as in rounds 3-4;
                                            // round 5, one box: potrf n = 12 288 / 16 384 13.80 / 28.51 -> 13.45 / 27.79 ms with 2-3; n = 32 768, whose groups are K = 768: 191.8 -> 200.1 ms with 3 -- so 2)
     int heads_beside_rows = 0;             // CIMRGP_HEADS_ROWS: the combined head + bulk launch also while the carried rows are running (round 5, rows on 192 units: 137.2 -> 135.4 / 134.3 posteriors/s: off)
-    int post_final = 1;                    // CIMRGP_POST_FINAL: the look-ahead's chain posts "panel final" in a device word and a gate on the update's queue waits for it (0: an event between the queues, rounds 1-4)
+    int post_final = 0;                    // CIMRGP_POST_FINAL: the look-ahead's chain posts "panel final" in a device word and a gate on the update's queue waits for it
+                                           // (0: an event between the queues, rounds 1-4).  Round 5: potrf n = 8192 5.43 -> 5.38 ms, the step unchanged -- and OFF, because
+                                           // rocprofv3's counter passes serialise kernels in the order their QUEUES become ready, not in submission order: the gate, first in
+                                           // its queue the moment the previous update ends, is run before the chain's remaining kernels and k_post three deep in theirs, and
+                                           // waits out its 2-s watchdog.  (The chain's own gate never meets that: the update it waits for is ready long before it.)
     int head_direct_max_rounds = 0;        // CIMRGP_HEAD_DIRECT: a head-first persistent update of at most this many rounds stores its head tiles at the end of their own pass (0: always streamed under the next pass)
     int pers_flex_cus = 0;                 // CIMRGP_PERS_FLEX: a persistent update may take up to this many units beyond its share when that saves a whole round of tiles ...
     int pers_flex_min_rounds = 7;          // CIMRGP_PERS_FLEX_MIN: ... of a launch of at least this many rounds.  OFF: measured in round 5 (profiles/r05_flex_scan.txt): the updates
