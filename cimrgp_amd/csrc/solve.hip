@@ -33,6 +33,7 @@ __global__ void k_transpose_nq(const T* __restrict__ src, T* __restrict__ dst, i
 
 constexpr int PW = CIMRGP_NB;      // panel width of the skinny solves (256)
 constexpr int ST = 1024;           // threads per workgroup of the skinny solves
+constexpr int FWD_ROWS = ST / 64;  // rows per workgroup of k_fwd_update (a wave per row)
 
 // ---------------------------------------------------------------------------
 // Q = number of right-hand sides at compile time: a run-time `if (c < q)` inside the load loops
@@ -42,8 +43,8 @@ constexpr int ST = 1024;           // threads per workgroup of the skinny solves
 //   k_fwd_alpha   z_p = L_pp^-1 w_p = invT_p^T w_p  (column sums over the rows <= column of the upper
 //                 triangular invT_p): 16 workgroups x 16 columns, 64 row parts of 4 rows per column,
 //                 fixed-order reduction in LDS;
-//   k_fwd_update  w[rows below the panel] -= L[rows, panel] z_p : 64 rows per workgroup, 16 lanes per
-//                 row, z_p (w x Q) read once per workgroup.
+//   k_fwd_update  w[rows below the panel] -= L[rows, panel] z_p : 16 rows per workgroup, a wave per
+//                 row (round 5; 64 rows of 16 lanes before), z_p (w x Q) read once per workgroup.
 // ---------------------------------------------------------------------------
 template <typename T, int Q>
 __global__ __launch_bounds__(ST)
@@ -82,27 +83,33 @@ void k_fwd_alpha(const T* __restrict__ invT, int n, const T* __restrict__ work, 
     }
 }
 
+// Round 5: 16 rows per workgroup, a whole wave per row (4 elements per lane) instead of 64 rows x 16 lanes: a workgroup
+// streams 32 KB of L instead of 128 KB and four times as many share a step (the step's time is one workgroup's time).
 template <typename T, int Q>
 __global__ __launch_bounds__(ST)
 void k_fwd_update(const T* __restrict__ L, int64_t ld, int n, T* __restrict__ work, const T* __restrict__ zp, int k0, int w)
 {
+    constexpr int EPL = PW / 64;                                  // elements per lane: a 256-column panel row over one wave
     __shared__ T zs[Q][PW];
     const int tid = threadIdx.x;
-    const int l16 = tid & 15, slot = tid >> 4;
-    const int r = k0 + w + blockIdx.x * 64 + slot;
-    T lv[16];
+    const int lane = tid & 63, slot = tid >> 6;                   // 16 rows per workgroup
+    const int r = k0 + w + blockIdx.x * FWD_ROWS + slot;
+    T lv[EPL];
+    T wold[Q];
+#pragma unroll
+    for (int c = 0; c < Q; ++c) wold[c] = (lane == 0 && r < n) ? work[(int64_t)c * n + r] : (T)0;    // requested up front
     if (r < n) {
-        const T* lp = L + (int64_t)r * ld + k0 + l16 * 16;
+        const T* lp = L + (int64_t)r * ld + k0 + lane * EPL;
         if (w == PW) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) lv[e] = lp[e];
+            for (int e = 0; e < EPL; ++e) lv[e] = lp[e];
         } else {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) lv[e] = (l16 * 16 + e < w) ? lp[e] : (T)0;
+            for (int e = 0; e < EPL; ++e) lv[e] = (lane * EPL + e < w) ? lp[e] : (T)0;
         }
     } else {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) lv[e] = (T)0;
+        for (int e = 0; e < EPL; ++e) lv[e] = (T)0;
     }
     for (int e = tid; e < Q * PW; e += ST) {
         const int c = e / PW, u = e - c * PW;
@@ -113,12 +120,10 @@ void k_fwd_update(const T* __restrict__ L, int64_t ld, int n, T* __restrict__ wo
     for (int c = 0; c < Q; ++c) {
         T sv = (T)0;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) sv += lv[e] * zs[c][l16 * 16 + e];
-        sv += __shfl_xor(sv, 8, 16);
-        sv += __shfl_xor(sv, 4, 16);
-        sv += __shfl_xor(sv, 2, 16);
-        sv += __shfl_xor(sv, 1, 16);
-        if (l16 == 0 && r < n) work[(int64_t)c * n + r] -= sv;
+        for (int e = 0; e < EPL; ++e) sv += lv[e] * zs[c][lane * EPL + e];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sv += __shfl_xor(sv, off, 64);
+        if (lane == 0 && r < n) work[(int64_t)c * n + r] = wold[c] - sv;
     }
 }
 
@@ -413,7 +418,7 @@ int potrs_run(const T* l, int64_t n, int64_t ld, const T* ws, T* rhs, int q, T* 
     for (int64_t k0 = 0; k0 < n && !backward_only; k0 += PW) {
         const int w = (int)((n - k0 < PW) ? (n - k0) : PW);
         const int64_t below = n - (k0 + w);
-        const unsigned grid = (unsigned)((below + 63) / 64);
+        const unsigned grid = (unsigned)((below + FWD_ROWS - 1) / FWD_ROWS);
         CIMRGP_Q_SWITCH(q, hipLaunchKernelGGL((k_fwd_alpha<T, QQ>), dim3((unsigned)((w + 15) / 16)), dim3(ST), 0, st,
                                               invT, (int)n, (const T*)work, res, (int)k0, w));
         CIMRGP_LAUNCH_CHECK(fn);
