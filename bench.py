@@ -430,7 +430,10 @@ def main():
                 pending[si].wait()
                 pending[si] = None
             return
-        s_front, s_factor, s_solve = streams
+        # a step that waits for its collective inside overlaps nothing with the next one: its front end stays on the
+        # factorisation's stream (the front queue is for pipelining: on it the start of a factorisation runs one-queue style,
+        # which only pays beside the previous factorisation's tail)
+        s_front, s_factor, s_solve = (streams[1], streams[1], streams[2]) if wait_inside else streams
         # the set comes back after nsets steps: its collective (started nsets steps ago) and its solve are waited for by
         # the front stream, not by the host
         with torch.cuda.stream(s_front):
@@ -442,7 +445,7 @@ def main():
             for t in b["others"]:
                 t.zero_()
         dev.block_posterior(xd, yd, xsd, ell, sf2, noise, b["kbuf"], b["wbuf"], b["ws"], b["info"], b["alpha"], b["zbuf"],
-                            b["mean"], b["var"], scratch=b["scratch"], streams=streams)
+                            b["mean"], b["var"], scratch=b["scratch"], streams=(s_front, s_factor, s_solve))
         with torch.cuda.stream(s_solve):
             pending[si] = reduce_begin(b["fused"], s_solve)                               # the one collective
             if wait_inside and pending[si] is not None:

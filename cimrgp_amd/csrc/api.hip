@@ -47,6 +47,9 @@ const Knobs& knobs()
         v.head_direct_max_rounds = (int)num("CIMRGP_HEAD_DIRECT", v.head_direct_max_rounds);
         v.post_final = (int)num("CIMRGP_POST_FINAL", v.post_final);
         v.heads_beside_rows = (int)num("CIMRGP_HEADS_ROWS", v.heads_beside_rows);
+        v.early_first_panel = (int)num("CIMRGP_EARLY_PANEL", v.early_first_panel);
+        v.early_panels = (int)num("CIMRGP_EARLY_PANELS", v.early_panels);
+        v.early_cus = (int)num("CIMRGP_EARLY_CUS", v.early_cus);
         v.pers_flex_cus = (int)num("CIMRGP_PERS_FLEX", v.pers_flex_cus);
         v.pers_flex_min_rounds = (int)num("CIMRGP_PERS_FLEX_MIN", v.pers_flex_min_rounds);
         v.rows_fused_tail = (int)num("CIMRGP_ROWS_FUSED", v.rows_fused_tail);
@@ -236,7 +239,7 @@ int block_posterior_typed(const void* x, int64_t n, int d, const void* y, int q,
     if (!rc && ns > 0) rc = rbf_gram_run<T>((const T*)xs, ns, (const T*)x, n, d, ell, sf2, 0.0, wt, ldw, false, false, s_front);
     if (!rc) rc = rhs_rows_run<T>((const T*)y, n, q, wt + ns * ldw, ldw, s_front);
     if (!rc) rc = hand_over(s_front, st);
-    if (!rc) rc = potrf_run<T>((T*)k, n, ldk, (T*)ws, info, wt, ns + q, ldw, st);
+    if (!rc) rc = potrf_run<T>((T*)k, n, ldk, (T*)ws, info, wt, ns + q, ldw, st, s_front);
     if (!rc) rc = hand_over(st, s_solve);
     // Safety net 2: two buffer sets in rotation need no ordering by the caller: behind its factorisation `st` waits for
     // the solve stage of the PREVIOUS call on the same pair of streams (finished long ago: it ran beside this

@@ -186,6 +186,11 @@ struct Knobs {
     int chain_cus = 32;                    // CIMRGP_CHAIN_CUS: compute units the bulk update leaves to the panel chain (look-ahead phase)
     int pers_max_chunks = 2;               // CIMRGP_PERS_CHUNKS: the persistent update takes K up to this many panels (256 columns each) in one pass per tile (1: K = 256 only, as in rounds 3-4;
                                            // round 5, one box: potrf n = 12 288 / 16 384 13.80 / 28.51 -> 13.45 / 27.79 ms with 2-3; n = 32 768, whose groups are K = 768: 191.8 -> 200.1 ms with 3 -- so 2)
+    int early_first_panel = 1;             // CIMRGP_EARLY_PANEL: a staged call whose front end ran on the context's chain queue factors its first panel there, in queue order (0: behind the factorisation's stream)
+    int early_panels = 8;                  // CIMRGP_EARLY_PANELS: ... and this many further panels (update + next panel) one-queue style on the chain queue before the
+                                           // look-ahead schedule takes over.  Round 5, one box (profiles/r05_early_panels.txt): 0 / 2 / 4 / 6 / 8 / 10 / 12 / 14 ->
+                                           // 137.7 / 139.8 / 140.5 / 143.1 / 143.6 / 143.8 / 141.5 / 138.8 posteriors/s
+    int early_cus = 0;                     // CIMRGP_EARLY_CUS: compute units of those early updates (0: the look-ahead phase's share)
     int heads_beside_rows = 0;             // CIMRGP_HEADS_ROWS: the combined head + bulk launch also while the carried rows are running (round 5, rows on 192 units: 137.2 -> 135.4 / 134.3 posteriors/s: off)
     int post_final = 0;                    // CIMRGP_POST_FINAL: the look-ahead's chain posts "panel final" in a device word and a gate on the update's queue waits for it
                                            // (0: an event between the queues, rounds 1-4).  Round 5: potrf n = 8192 5.43 -> 5.38 ms, the step unchanged -- and OFF, because
@@ -211,7 +216,7 @@ hipStream_t front_queue_for(hipStream_t st);
 // --------------------------------------------------------- host launchers ----
 // potrf.hip
 template <typename T> int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m, int64_t ldb,
-                                    hipStream_t st);
+                                    hipStream_t st, hipStream_t ready_on = nullptr);
 // `batch` equal-sized factorisations in the same launches (strides in elements / ints)
 struct PotrfBatch { int count = 1; int64_t sk = 0, sws = 0, sb = 0; };
 template <typename T> int potrf_batched_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m, int64_t ldb,

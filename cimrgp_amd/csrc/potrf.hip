@@ -2367,6 +2367,7 @@ struct LookAhead {
     hipStream_t owner = nullptr;       // the caller stream this context was created for
     bool gate_ok = false;              // this context may hold a kernel that waits for another one (k_gate): the device's first context only
     std::mutex enqueue;                // one factorisation at a time enqueues on this context's queues
+    hipEvent_t last_done = nullptr;    // behind the latest look-ahead factorisation on this context (recorded on its caller's stream)
 };
 std::mutex g_reg_mutex;                // guards g_ctx and context creation
 std::vector<LookAhead*> g_ctx[16];     // per device; contexts live as long as the process
@@ -2440,6 +2441,7 @@ int destroy_contexts()
             for (hipStream_t q : {la->side, la->bulk, la->rows, la->rows_far})
                 if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
             for (hipEvent_t e : la->ev) (void)hipEventDestroy(e);
+            if (la->last_done) (void)hipEventDestroy(la->last_done);
             if (la->flag) (void)hipFree(la->flag);
             delete la;
         }
@@ -2554,15 +2556,20 @@ static int build_invT(const T* kmat, int64_t n, int64_t ld, T* ws, hipStream_t s
     do { hipError_t e__ = (call); if (e__ != hipSuccess) return check_hip(e__, "cimrgp_potrf", what); } while (0)
 
 template <typename T>
-int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m, int64_t ldb, hipStream_t st)
+int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m, int64_t ldb, hipStream_t st, hipStream_t ready_on)
 {
     const bool rows = (b != nullptr && m > 0);
-    CIMRGP_HIP_TRY(hipMemsetAsync(info, 0, sizeof(int32_t), st), "hipMemsetAsync(info)");
     const int64_t npanels = (n + CIMRGP_NB - 1) / CIMRGP_NB;
     // Small matrices: one queue.  Measured in round 1 (whole potrf, one queue vs look-ahead): n = 2048:
     // 1.23 vs 1.37 ms, 4096: 2.80 vs 3.04 -- and independent blocks of a layer run concurrently on
     // their callers' streams, which fills the machine better than look-ahead inside each of them.
     LookAhead* la = (n > SINGLE_QUEUE_MAX && npanels > 2) ? acquire_ctx(st) : nullptr;
+    // `ready_on`: the queue on which the caller wrote K and B, when that is this context's chain queue (cimrgp_front_queue) and
+    // not `st`.  The FIRST panel's chain then follows them there in queue order instead of waiting for `st` -- for a caller that
+    // pipelines independent blocks it runs beside the previous factorisation's latency-bound tail, not behind it (~100 us of a
+    // nearly idle machine per factorisation).  Everything after it waits for `st` as before.
+    const bool early = la != nullptr && ready_on != nullptr && ready_on == la->side && ready_on != st && knobs().early_first_panel != 0;
+    CIMRGP_HIP_TRY(hipMemsetAsync(info, 0, sizeof(int32_t), early ? la->side : st), "hipMemsetAsync(info)");
     if (la == nullptr) {
         int rc0 = fused_sweep<T>(k, n, ld, ws, info, b, m, ldb, PotrfBatch(), st);
         return rc0 ? rc0 : build_invT<T>(k, n, ld, ws, st);
@@ -2597,7 +2604,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     bool final_posted = false;                         // ... the panel this iteration starts from among them
     hipEvent_t ev_start = la->ev[ne++];
     CIMRGP_HIP_TRY(hipEventRecord(ev_start, st), "hipEventRecord");
-    CIMRGP_HIP_TRY(hipStreamWaitEvent(sp, ev_start, 0), "hipStreamWaitEvent");
+    if (!early) CIMRGP_HIP_TRY(hipStreamWaitEvent(sp, ev_start, 0), "hipStreamWaitEvent");
     if (sb != st) CIMRGP_HIP_TRY(hipStreamWaitEvent(sb, ev_start, 0), "hipStreamWaitEvent");
     int rc = factor_panel<T>(k, n, ld, ws, info, 0, (n < CIMRGP_NB) ? n : CIMRGP_NB, sp, true);
     if (rc) return rc;
@@ -2738,7 +2745,37 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
         rows_next = k1;
         return 0;
     };
-    for (int64_t k0 = 0; k0 < n; k0 += CIMRGP_NB) {
+    int64_t k_begin = 0;
+    if (early) {
+        // ... and knobs().early_panels more panels one-queue style (update of everything right of panel p, then panel p+1, in
+        // queue order on the chain queue): work of THIS factorisation done while the previous one's tail leaves the machine
+        // two-thirds idle.  From panel k_begin on the look-ahead schedule below takes over, behind `st` as always.
+        // (only while the context's previous factorisation is still in flight when this one is enqueued: with the machine
+        //  to itself a factorisation is better off with look-ahead from the first panel on)
+        const bool prev_in_flight = la->last_done != nullptr && hipEventQuery(la->last_done) == hipErrorNotReady;
+        (void)hipGetLastError();                     // "not ready" is an answer, not an error for the launch checks below to find
+        const int np_early = (sizeof(T) == 8 && prev_in_flight) ? knobs().early_panels : 0;
+        GemmBatch early_gb = bulk_gb;
+        if (knobs().early_cus >= 8) early_gb.pers = knobs().early_cus;
+        for (int p = 0; p < np_early && rc == 0; ++p) {
+            const int64_t k0e = (int64_t)p * CIMRGP_NB, k1e = k0e + CIMRGP_NB;
+            if (n - k1e < 4 * CIMRGP_NB || (n - k1e) % 128 != 0) break;
+            const double mme = (double)(n - k1e);
+            hipEvent_t rec = rec_open(sp, mme * (mme + 1.0) * (double)CIMRGP_NB, (mme * (mme + 1.0) + mme * (double)CIMRGP_NB) * (double)sizeof(T));
+            rc = gemm_nt_sub<T>(k + k1e * ld + k1e, ld, k + k1e * ld + k0e, ld, k + k1e * ld + k0e, ld, n - k1e, n - k1e, (int)CIMRGP_NB, true, sp, early_gb);
+            if (rec) (void)hipEventRecord(rec, sp);
+            if (rc) return rc;
+            rc = factor_panel<T>(k, n, ld, ws, info, k1e, CIMRGP_NB, sp, true);
+            if (rc) return rc;
+            k_begin = k1e;
+        }
+        if (k_begin > 0) {
+            ev_panel = la->ev[ne++];
+            CIMRGP_HIP_TRY(hipEventRecord(ev_panel, sp), "hipEventRecord");
+        }
+        CIMRGP_HIP_TRY(hipStreamWaitEvent(sp, ev_start, 0), "hipStreamWaitEvent");
+    }
+    for (int64_t k0 = k_begin; k0 < n; k0 += CIMRGP_NB) {
         const int64_t w  = (n - k0 < CIMRGP_NB) ? (n - k0) : CIMRGP_NB;
         const int64_t k1 = k0 + w;
         // With carried rows (round 3): the last rows_beside_tail_below columns are factored by the same one-queue fused
@@ -2987,6 +3024,11 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     return build_invT<T>(k, n, ld, ws, st);
     };   // body
     const int rc_body = body();
+    if (rc_body == 0) {
+        // (a failed record only costs the next call its early panels)
+        if (la->last_done == nullptr && hipEventCreateWithFlags(&la->last_done, hipEventDisableTiming) != hipSuccess) la->last_done = nullptr;
+        if (la->last_done != nullptr) (void)hipEventRecord(la->last_done, st);
+    }
     if (rc_body != 0) {
         // failed enqueue: the caller's stream waits for everything that did get queued (errors of the join itself
         // cannot improve on the one being reported)
@@ -3048,8 +3090,8 @@ int solve_rows_run(const T* l, int64_t n, int64_t ld, const T* ws, T* b, int64_t
     return panel_sweep<T, false>(const_cast<T*>(l), n, ld, const_cast<T*>(ws), nullptr, b, m, ldb, st, bt);
 }
 
-template int potrf_run<double>(double*, int64_t, int64_t, double*, int32_t*, double*, int64_t, int64_t, hipStream_t);
-template int potrf_run<float>(float*, int64_t, int64_t, float*, int32_t*, float*, int64_t, int64_t, hipStream_t);
+template int potrf_run<double>(double*, int64_t, int64_t, double*, int32_t*, double*, int64_t, int64_t, hipStream_t, hipStream_t);
+template int potrf_run<float>(float*, int64_t, int64_t, float*, int32_t*, float*, int64_t, int64_t, hipStream_t, hipStream_t);
 template int potrf_batched_run<double>(double*, int64_t, int64_t, double*, int32_t*, double*, int64_t, int64_t, PotrfBatch, hipStream_t);
 template int potrf_batched_run<float>(float*, int64_t, int64_t, float*, int32_t*, float*, int64_t, int64_t, PotrfBatch, hipStream_t);
 template int solve_rows_run<double>(const double*, int64_t, int64_t, const double*, double*, int64_t, int64_t, hipStream_t, PotrfBatch);

@@ -1,0 +1,13 @@
+#!/bin/bash
+# round-5 GPU call 30: the first panel of a staged call on the chain queue behind its own front end (CIMRGP_EARLY_PANEL), one box
+mkdir -p gpurun_out
+T=$PWD/cimrgp_amd/libcimrgp_tuning.so
+timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "posterior or staged" 2>&1 | tail -2 || exit 1
+one() { echo -n "$* : "; env CIMRGP_LIB_PATH=$T "$@" python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['whole_step']['frac'], d['stage_ms']['potrf_alone'])"; }
+{
+for rep in 1 2 3; do
+one CIMRGP_EARLY_PANEL=0
+one CIMRGP_EARLY_PANEL=1
+done
+} | tee gpurun_out/r05_early_panel.txt
+python3 bench.py --steps 6 --warmup 2 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('parity', d.get('parity_ok'), d.get('parity_rel_err_mean'), d.get('parity_rel_err_var'), d['value'])" | tee -a gpurun_out/r05_early_panel.txt
