@@ -190,7 +190,7 @@ struct Knobs {
     int early_panels = 8;                  // CIMRGP_EARLY_PANELS: ... and this many further panels (update + next panel) one-queue style on the chain queue before the
                                            // look-ahead schedule takes over.  Round 5, one box (profiles/r05_early_panels.txt): 0 / 2 / 4 / 6 / 8 / 10 / 12 / 14 ->
                                            // 137.7 / 139.8 / 140.5 / 143.1 / 143.6 / 143.8 / 141.5 / 138.8 posteriors/s
-    int early_cus = 0;                     // CIMRGP_EARLY_CUS: compute units of those early updates (0: the look-ahead phase's share)
+    int early_cus = 256;                   // CIMRGP_EARLY_CUS: compute units of those early updates (0: the look-ahead phase's share; no chain of their own factorisation runs beside them: 224 -> 256: 144.4 -> 145.0, 145.1 -> 146.1)
     int heads_beside_rows = 0;             // CIMRGP_HEADS_ROWS: the combined head + bulk launch also while the carried rows are running (round 5, rows on 192 units: 137.2 -> 135.4 / 134.3 posteriors/s: off)
     int post_final = 0;                    // CIMRGP_POST_FINAL: the look-ahead's chain posts "panel final" in a device word and a gate on the update's queue waits for it
                                            // (0: an event between the queues, rounds 1-4).  Round 5: potrf n = 8192 5.43 -> 5.38 ms, the step unchanged -- and OFF, because
