@@ -141,8 +141,13 @@ int cimrgp_block_posterior_staged(int dtype, const void* x_dev, int64_t n, int d
 int cimrgp_solve_queue(void* stream, void** queue_out);
 /* A queue for stream_front: the queue of `stream`'s look-ahead context that falls idle before a factorisation on
  * `stream` ends (the last third of a factorisation runs on one queue).  The Gram matrices of the NEXT independent block,
- * enqueued there, run beside that latency-bound tail instead of behind it.  The caller orders the front end's inputs
- * on *queue_out itself (the staged call orders its own buffer sets).  *queue_out = stream when no context can be had. */
+ * enqueued there, run beside that latency-bound tail instead of behind it -- and so does the START of that block's
+ * factorisation: a staged call with this queue as stream_front factors its first panel there, in queue order behind its
+ * own front end, and, while the previous factorisation on `stream` is still in flight when the call is made, its next
+ * eight panels one after the other (update, next panel) before the look-ahead schedule takes over on `stream`.  For
+ * consecutive INDEPENDENT blocks only (two buffer sets in rotation); a call that has the machine to itself gains nothing
+ * from it.  The caller orders the front end's inputs on *queue_out itself (the staged call orders its own buffer sets).
+ * *queue_out = stream when no context can be had. */
 int cimrgp_front_queue(void* stream, void** queue_out);
 /* `batch` equal-sized factorisations -- the blocks of one layer (independent over regions,
  * Posteriors.py:35-59) -- in the SAME kernel launches: matrix i starts k_stride elements after
