@@ -49,7 +49,9 @@ def main():
             tg = sym[int(sys.argv[3]) - 1]["s"]
         else:
             tg = rows[start]["s"]
-        rows = [r for r in rows if tg - 400_000 <= r["s"] <= tg + 900_000]
+        before_us = int(sys.argv[4]) if len(sys.argv) > 4 else 400     # (argv[4], argv[5]: the window in us before / after it)
+        after_us = int(sys.argv[5]) if len(sys.argv) > 5 else 900
+        rows = [r for r in rows if tg - before_us * 1000 <= r["s"] <= tg + after_us * 1000]
         t0 = tg
         print("# window around the last Gram build (time 0): the previous step's tail and solve stage | the next step's front end and first panels")
     else:
