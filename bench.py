@@ -287,6 +287,9 @@ def main():
     ap.add_argument("--pipeline", type=int, default=-1, choices=[-1, 0, 1],
                     help="1: consecutive (independent) blocks pipelined over three streams and three buffer sets "
                          "(cimrgp_block_posterior_staged); 0: one stream, one set; default: 1 unless ranks share one GPU")
+    ap.add_argument("--front-queue", type=int, default=int(os.environ.get("CIMRGP_BENCH_FRONT", "1")), choices=[0, 1],
+                    help="(pipelined steps) 1: the front end and the start of step i+1's factorisation on the context's chain queue "
+                         "(cimrgp_front_queue), beside the last panels of step i; 0: behind step i on its stream (rounds 1-4)")
     ap.add_argument("--nccl-world1", action="store_true",
                     help="one rank, an RCCL communicator of one created, the step's reduce goes through RCCL unconditionally")
     ap.add_argument("--comm", default="cabi", choices=["cabi", "torch"],
@@ -396,7 +399,7 @@ def main():
         cur = torch.cuda.current_stream()
         # front end of step i+1 on the context's chain queue, which falls idle in the last third of step i's factorisation
         # (cimrgp_front_queue; one box, three alternating pairs: 136.8 / 136.9 / 136.6 -> 137.4 / 137.2 / 137.3 posteriors/s)
-        streams = (dev.front_queue(cur) if os.environ.get("CIMRGP_BENCH_FRONT", "1") == "1" else cur, cur, dev.solve_queue(cur))
+        streams = (dev.front_queue(cur) if args.front_queue else cur, cur, dev.solve_queue(cur))
     pending = [None] * nsets                 # the set's collective in flight
     done = [None] * nsets                    # (pipeline) the set's last reader on the solve stream
     step_no = [0]
@@ -582,7 +585,8 @@ def main():
                        "parallelism": "independent partitions, 1 all-reduce/step (started at the end of a step, waited for by the stream at the start of the next)",
                        "backend": ((rehearsal or ("rccl through the C ABI (cimrgp_allreduce_sum on the step's solve queue); control plane gloo"
                                                    if comm is not None else "nccl")) if td.is_initialized() else "none"),
-                       "rows_queues": int(lib.cimrgp_get_rows_queues())},
+                       "rows_queues": int(lib.cimrgp_get_rows_queues()),
+                       "front_queue": bool(pipeline and args.front_queue)},
             "reduce_selfcheck_max_abs_diff": reduce_diff,
             "cholesky_gflops": chol_gflops,
             "cholesky_frac_of_peak": chol_gflops / 1e3 / peak,
