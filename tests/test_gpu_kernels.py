@@ -591,7 +591,10 @@ def test_block_posterior_staged_edge_cases(dev, dt, n, ns):
     ref = run(None)
     same = run((cur, cur, cur))
     piped = run((cur, cur, dev.solve_queue(cur)))
-    for got in (same, piped):
+    # ... and with the front end on cimrgp_front_queue: the first panel of the factorisation then follows it on that queue
+    # (n = 6144: look-ahead; the small size owns no context and gets its own stream back)
+    fronted = run((dev.front_queue(cur), cur, dev.solve_queue(cur)))
+    for got in (same, piped, fronted):
         assert all(torch.equal(a, b) for a, b in zip(ref, got))
     if ns:
         assert float(ref[3].min()) != 0.5 or float(ref[3].max()) != 0.5      # accumulated onto the 0.5 / 0.25 fills
