@@ -323,6 +323,7 @@ def main():
     # --comm torch: backend nccl, the step's all_reduce through torch.distributed (the round-4 form).
     cabi = (args.comm == "cabi") and not rehearsal and args.config == 2
     comm = None
+    fallback_group = None                  # torch.distributed nccl group for the data path when the C-ABI communicator failed
     if args.gpus > 1 or world > 1 or args.nccl_world1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -333,7 +334,24 @@ def main():
             td.init_process_group("gloo", rank=rank, world_size=world)
             ident = [_lib.Comm.unique_id() if rank == 0 else None]
             td.broadcast_object_list(ident, src=0)
-            comm = _lib.Comm(world, rank, ident[0])           # collective; binds the current device (set above)
+            # collective; binds the current device (set above).  Should the communicator fail on ANY rank (it has only
+            # ever been created for a world of one: no multi-GPU node has been available), every rank falls back to
+            # torch.distributed's nccl for the data path -- slower by the fifth queue, but a measured line
+            try:
+                if os.environ.get("CIMRGP_BENCH_FAIL_COMM"):      # test hook (tests/test_gpu_configs.py): exercise the fallback
+                    raise RuntimeError("simulated failure")
+                comm = _lib.Comm(world, rank, ident[0])
+                ok = 1
+            except Exception as exc:                              # noqa: BLE001 -- whatever it is, the ranks decide together
+                sys.stderr.write("bench.py: rank %d: C-ABI communicator failed (%s): falling back to torch.distributed nccl\n" % (rank, exc))
+                comm, ok = None, 0
+            flag = torch.tensor([ok], dtype=torch.int32)
+            td.all_reduce(flag, op=td.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if comm is not None:
+                    comm.close()
+                    comm = None
+                fallback_group = td.new_group(backend="nccl")
         else:
             # device_id: the communicator is bound to this rank's GPU up front (no guessing in barrier())
             td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -411,7 +429,7 @@ def main():
         if comm is not None:
             comm.allreduce_sum((_lib.F64 if args.dtype == "f64" else _lib.F32), fused.data_ptr(), fused.numel(), stream.cuda_stream)
             return None
-        return dist.allreduce_sum_begin(fused, force=args.nccl_world1)
+        return dist.allreduce_sum_begin(fused, group=fallback_group, force=args.nccl_world1)
 
     def step(wait_inside=False):
         si = step_no[0] % nsets
@@ -584,7 +602,8 @@ def main():
                        "partitions_per_gpu": 1,
                        "parallelism": "independent partitions, 1 all-reduce/step (started at the end of a step, waited for by the stream at the start of the next)",
                        "backend": ((rehearsal or ("rccl through the C ABI (cimrgp_allreduce_sum on the step's solve queue); control plane gloo"
-                                                   if comm is not None else "nccl")) if td.is_initialized() else "none"),
+                                                   if comm is not None else ("nccl (fallback: the C-ABI communicator could not be created)"
+                                                                             if fallback_group is not None else "nccl"))) if td.is_initialized() else "none"),
                        "rows_queues": int(lib.cimrgp_get_rows_queues()),
                        "front_queue": bool(pipeline and args.front_queue)},
             "reduce_selfcheck_max_abs_diff": reduce_diff,

@@ -354,6 +354,16 @@ def test_bench_step_under_rccl_world_of_one():
     assert "cimrgp_block_posterior" in plain["step_is"]
 
 
+def test_bench_falls_back_to_torch_nccl_when_the_c_abi_communicator_fails():
+    """bench.py's N > 1 step creates the C ABI's RCCL communicator on every rank; if that fails on any of them (it has never
+    seen more than one GPU) all ranks agree -- over the gloo control plane -- to reduce through torch.distributed's nccl
+    instead, so that a scaling run still yields a line.  Exercised here with a simulated failure in a world of one."""
+    rec = _run_bench(["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--nccl-world1"], env_extra={"CIMRGP_BENCH_FAIL_COMM": "1"})
+    assert rec["config"]["backend"].startswith("nccl (fallback")
+    assert rec["reduce_overlapped"] is True and rec["reduce_selfcheck_max_abs_diff"] == 0.0
+    assert rec["value"] > 0
+
+
 def test_c_abi_collective_world_of_one(ca):
     """The boundary's own collective (include/cimrgp.h: cimrgp_comm_unique_id / cimrgp_comm_create /
     cimrgp_allreduce_sum), ctypes only, no torch.distributed: a world of one on this GPU reduces the fused
