@@ -36,6 +36,7 @@ const Knobs& knobs()
         v.chain_mode = !c ? 0 : (c[0] == 's' ? 1 : c[0] == 'w' ? 2 : c[0] == 'q' ? 3 : 0);
         v.tail_below = num("CIMRGP_TAIL_BELOW", v.tail_below);
         v.rows_start_below = num("CIMRGP_ROWS_START", v.rows_start_below);
+        v.rows_start_below_early = num("CIMRGP_ROWS_START_EARLY", v.rows_start_below_early);
         v.head_first_above = num("CIMRGP_HEAD_FIRST", v.head_first_above);
         v.far_pair_above = num("CIMRGP_FAR_PAIR", v.far_pair_above);
         v.fused_head0 = (int)num("CIMRGP_HEAD0", v.fused_head0);

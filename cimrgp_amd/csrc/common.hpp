@@ -163,6 +163,7 @@ struct Knobs {
     int chain_mode = 0;                    // CIMRGP_CHAIN = split | wide | quad: 1 round-1 links / 2 nine-wave / 3 four-wave (0: by context)
     int64_t tail_below = 4864;             // CIMRGP_TAIL_BELOW: trailing matrix at or below this: finish on one queue
     int64_t rows_start_below = 6144;       // CIMRGP_ROWS_START: carried rows start once the trailing matrix is smaller
+    int64_t rows_start_below_early = 5632; // CIMRGP_ROWS_START_EARLY: ... in a factorisation that started with early panels (round 5, one box: 6144 / 5632 -> 144.1 / 145.4, 144.5 / 145.1, 144.3 / 145.2; a lone factorisation: 136.8 / 134.4 the other way)
     int64_t head_first_above = 1ll << 30;  // CIMRGP_HEAD_FIRST: bulk update waits for the head above this (off)
     int64_t far_pair_above = 8192;         // CIMRGP_FAR_PAIR: far part updated once per group of panels above this
     int fused_head0 = 1;                   // CIMRGP_HEAD0: first diagonal block of a panel takes its head update itself

@@ -2649,10 +2649,13 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
     // switch to the one-queue tail they catch up with the whole machine to themselves (`force`), and from
     // there on they ride in the chain's launches like the factorisation's own updates (fused_sweep).
     const bool rows_fused = rows && knobs().rows_fused_tail != 0;
+    // trailing columns below which the carried rows start (set again below when this factorisation starts with early panels:
+    // beside the previous factorisation's last panels the rows do better starting two panels later)
+    int64_t rows_start = knobs().rows_start_below;
     auto rows_after_panel = [&](int64_t k0, int64_t k1, hipEvent_t ev_final, bool force = false) -> int {
         if (!rows) return 0;
         hipStream_t sq = la->rows;                     // always present (make_ctx: all queues or no context)
-        const int64_t rows_start_below = knobs().rows_start_below;
+        const int64_t rows_start_below = rows_start;
         const bool defer = rows_fused ? (k1 < n) : ((n - k1 > rows_start_below) && (k1 < n));
         if (defer && !force) return 0;
         CIMRGP_HIP_TRY(hipStreamWaitEvent(sq, ev_final, 0), "hipStreamWaitEvent");
@@ -2770,6 +2773,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
             k_begin = k1e;
         }
         if (k_begin > 0) {
+            rows_start = knobs().rows_start_below_early;
             ev_panel = la->ev[ne++];
             CIMRGP_HIP_TRY(hipEventRecord(ev_panel, sp), "hipEventRecord");
         }
@@ -2852,7 +2856,7 @@ int potrf_run(T* k, int64_t n, int64_t ld, T* ws, int32_t* info, T* b, int64_t m
         // 64 x 64 update as its prologue (as before) and the rest of the first 128 x 128 tile along as riders.
         // (not while the carried rows are running: their kernels hold compute units the persistent workgroups
         // of the combined launch -- head tiles included -- would have to wait for: 114 -> 109 posteriors/s)
-        const bool rows_running = rows && !rows_fused && !knobs().heads_beside_rows && (n - k1 <= knobs().rows_start_below);
+        const bool rows_running = rows && !rows_fused && !knobs().heads_beside_rows && (n - k1 <= rows_start);
         const int heads = (may_gate && knobs().chain_mode == 0 && !rows_running && w == CIMRGP_NB && wn == CIMRGP_NB && n > k2 && !grp_open() &&
                            group_size(n - k2 - ((n - k2 < CIMRGP_NB) ? (n - k2) : CIMRGP_NB), knobs().far_pair_above) == 1)
                               ? gemm_pers_head_tiles(n - k1, (int)w, (int)sizeof(T)) : 0;
